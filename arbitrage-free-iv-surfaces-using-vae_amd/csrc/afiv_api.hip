@@ -1,0 +1,289 @@
+// Host side of libafiv.so: the extern "C" entry points declared in include/afiv.h.
+// Creation calls allocate and fill device memory; execution calls only validate their
+// arguments and enqueue kernels on the caller's stream.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "afiv_internal.h"
+#include "laguerre144.inc"
+
+namespace {
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+int check_grid(const afiv_grid *g)
+{
+    if (!g) return AFIV_E_NULL;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AFIV_E_HIP;
+    if (dev != g->device) return AFIV_E_ARG;   // a grid is bound to the device it was created on
+    return AFIV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int afiv_version(void) { return AFIV_VERSION; }
+
+const char *afiv_error_string(int code)
+{
+    switch (code) {
+        case AFIV_OK: return "ok";
+        case AFIV_E_NULL: return "required pointer is NULL";
+        case AFIV_E_SHAPE: return "size out of supported range";
+        case AFIV_E_HIP: return "HIP runtime call or kernel launch failed";
+        case AFIV_E_ARG: return "bad argument (enum value, or object used on a different device)";
+        case AFIV_E_WORKSPACE: return "grid was created without the workspace this call needs";
+        default: return "unknown error";
+    }
+}
+
+int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *tau, int nT, double r,
+                     double q, int trunc_days, int64_t workspace_surfaces)
+{
+    if (!out || !logm || !tau) return AFIV_E_NULL;
+    *out = nullptr;
+    if (nK < 1 || nK > AFIV_MAX_STRIKES || nT < 1 || nT > AFIV_MAX_MATURITIES) return AFIV_E_SHAPE;
+    if (workspace_surfaces < 0) return AFIV_E_SHAPE;
+    const int nKpad = (nK + 15) / 16 * 16;
+
+    // Host-side constants use the host libm so that discount factors, forwards and strikes are
+    // the very doubles NumPy produces in the Python reference.
+    const size_t nd = (size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad;
+    std::vector<double> h(nd, 0.0);
+    double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
+           *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
+           *p_logm = p_dq + nT, *p_K = p_logm + nK, *p_tab = p_K + nK;
+    for (int t = 0; t < nT; ++t) {
+        p_tau[t] = tau[t];
+        // heston_model_ql.py:131: int(tau*365) days, Actual/365 Fixed
+        p_term[t] = trunc_days ? (double)((long)(tau[t] * 365.0)) / 365.0 : tau[t];
+        p_Dr[t] = 1.0 / std::exp(r * p_term[t]);
+        p_Dq[t] = 1.0 / std::exp(q * p_term[t]);
+        p_dd[t] = std::log(1.0) - std::log(p_Dr[t] / p_Dq[t]);
+        p_disc[t] = std::exp(-r * tau[t]);
+        p_fwd[t] = std::exp((r - q) * tau[t]);
+        p_dq[t] = std::exp(-q * tau[t]);
+    }
+    for (int k = 0; k < nK; ++k) {
+        p_logm[k] = logm[k];
+        p_K[k] = 1.0 * std::exp(logm[k]);       // heston_model_ql.py:171 with spot 1
+    }
+    // Strike tables for the contraction index m = 2*(j*144 + n) + c (c = 0: sin-alpha operand,
+    // c = 1: cos-alpha operand).  Row values per strike k, with sx = log K_k:
+    //   j = 0 (P1):   cos(x_n sx),      -sin(x_n sx)
+    //   j = 1 (P2): -K cos(x_n sx),    K sin(x_n sx)
+    // so that sum_m X[m] tab[m][k] = Dq P1 - K Dr P2 when X carries Dq / Dr.
+    for (int k = 0; k < nK; ++k) {
+        const double K = p_K[k];
+        const double sx = std::log(K);
+        for (int n = 0; n < AFIV_NQ_NODES; ++n) {
+            const double ang = AFIV_LAG_X[n] * sx;
+            const double c = std::cos(ang), s = std::sin(ang);
+            p_tab[(size_t)(2 * n + 0) * nKpad + k] = c;
+            p_tab[(size_t)(2 * n + 1) * nKpad + k] = -s;
+            p_tab[(size_t)(2 * (AFIV_NQ_NODES + n) + 0) * nKpad + k] = -K * c;
+            p_tab[(size_t)(2 * (AFIV_NQ_NODES + n) + 1) * nKpad + k] = K * s;
+        }
+    }
+
+    afiv_grid *g = new (std::nothrow) afiv_grid();
+    if (!g) return AFIV_E_HIP;
+    if (hipGetDevice(&g->device) != hipSuccess) { delete g; return AFIV_E_HIP; }
+    double *dev = nullptr;
+    if (hipMalloc((void **)&dev, nd * sizeof(double)) != hipSuccess) { delete g; return AFIV_E_HIP; }
+    if (hipMemcpy(dev, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev); delete g; return AFIV_E_HIP;
+    }
+    g->block = dev;
+    g->workspace = nullptr;
+    g->workspace_surfaces = 0;
+    if (workspace_surfaces > 0) {
+        const size_t bytes = (size_t)workspace_surfaces * nT * nK * sizeof(double);
+        if (hipMalloc((void **)&g->workspace, bytes) != hipSuccess) {
+            (void)hipFree(dev); delete g; return AFIV_E_HIP;
+        }
+        g->workspace_surfaces = workspace_surfaces;
+    }
+    GridView &v = g->v;
+    v.nT = nT; v.nK = nK; v.nKpad = nKpad; v.r = r; v.q = q;
+    v.tau = dev; v.term = v.tau + nT; v.dd = v.term + nT; v.Dq = v.dd + nT; v.Dr = v.Dq + nT;
+    v.disc_tau = v.Dr + nT; v.fwd_mult = v.disc_tau + nT; v.dq_tau = v.fwd_mult + nT;
+    v.logm = v.dq_tau + nT; v.Kmult = v.logm + nK; v.tab = v.Kmult + nK;
+    *out = g;
+    return AFIV_OK;
+}
+
+int afiv_grid_destroy(afiv_grid *g)
+{
+    if (!g) return AFIV_OK;
+    if (g->workspace) (void)hipFree(g->workspace);
+    if (g->block) (void)hipFree(g->block);
+    delete g;
+    return AFIV_OK;
+}
+
+int afiv_price(const afiv_grid *g, const double *params, int64_t N, double *ratio_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (N == 0) return AFIV_OK;
+    if (!params || !ratio_out) return AFIV_E_NULL;
+    return afiv_launch_price(g->v, params, N, ratio_out, as_stream(stream));
+}
+
+int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double spot, int variant,
+                     double *iv_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (N == 0) return AFIV_OK;
+    if (!ratio || !iv_out) return AFIV_E_NULL;
+    return afiv_launch_implied_vol(g->v, ratio, N, spot, variant, iv_out, as_stream(stream));
+}
+
+int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, int64_t N, double spot,
+                   int bs_form, int32_t *flags_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (bs_form != AFIV_VARIANT_A && bs_form != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (N == 0) return AFIV_OK;
+    if (!iv || !flags_out) return AFIV_E_NULL;
+    return afiv_launch_arb_check(g->v, iv, ratio, N, spot, bs_form, flags_out, as_stream(stream));
+}
+
+int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
+                 double *ratio_out, double *iv_out, int32_t *flags_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (N == 0) return AFIV_OK;
+    if (!params || !iv_out || !flags_out) return AFIV_E_NULL;
+    hipStream_t s = as_stream(stream);
+    const int64_t per = (int64_t)g->v.nT * g->v.nK;
+    if (ratio_out) {
+        if ((rc = afiv_launch_price(g->v, params, N, ratio_out, s))) return rc;
+        if ((rc = afiv_launch_implied_vol(g->v, ratio_out, N, spot, variant, iv_out, s))) return rc;
+        return afiv_launch_arb_check(g->v, iv_out, ratio_out, N, spot, variant, flags_out, s);
+    }
+    if (!g->workspace) return AFIV_E_WORKSPACE;
+    // Stream order makes the reuse of the workspace by consecutive chunks safe.
+    for (int64_t off = 0; off < N; off += g->workspace_surfaces) {
+        const int64_t n = (N - off < g->workspace_surfaces) ? N - off : g->workspace_surfaces;
+        if ((rc = afiv_launch_price(g->v, params + 5 * off, n, g->workspace, s))) return rc;
+        if ((rc = afiv_launch_implied_vol(g->v, g->workspace, n, spot, variant, iv_out + off * per, s))) return rc;
+        if ((rc = afiv_launch_arb_check(g->v, iv_out + off * per, g->workspace, n, spot, variant,
+                                        flags_out + 4 * off, s))) return rc;
+    }
+    return AFIV_OK;
+}
+
+int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w)
+{
+    if (!out || !w) return AFIV_E_NULL;
+    *out = nullptr;
+    static const int IN[4] = {12, 32, 64, 128}, OUT[4] = {32, 64, 128, 5};
+    for (int l = 0; l < 4; ++l)
+        if (!w->lin_w[l] || !w->lin_b[l]) return AFIV_E_NULL;
+    for (int l = 0; l < 3; ++l)
+        if (!w->bn_w[l] || !w->bn_b[l] || !w->bn_mean[l] || !w->bn_var[l]) return AFIV_E_NULL;
+    if (!w->param_mean || !w->param_std) return AFIV_E_NULL;
+    std::vector<float> h;
+    for (int l = 0; l < 4; ++l) {
+        const int in = IN[l], o = OUT[l];
+        for (int i = 0; i < in; ++i)
+            for (int j = 0; j < o; ++j) h.push_back(w->lin_w[l][(size_t)j * in + i]);   // transpose to input-major
+        for (int j = 0; j < o; ++j) h.push_back(w->lin_b[l][j]);
+        if (l < 3) {
+            // eval-mode BatchNorm1d as y = x*scale + shift (float arithmetic, as torch's CPU kernel)
+            std::vector<float> scale(o), shift(o);
+            for (int j = 0; j < o; ++j) {
+                const float invstd = 1.0f / std::sqrt(w->bn_var[l][j] + w->bn_eps);
+                scale[j] = invstd * w->bn_w[l][j];
+                shift[j] = w->bn_b[l][j] - w->bn_mean[l][j] * scale[j];
+            }
+            h.insert(h.end(), scale.begin(), scale.end());
+            h.insert(h.end(), shift.begin(), shift.end());
+        }
+    }
+    const size_t npacked = h.size();
+    for (int j = 0; j < 5; ++j) h.push_back(w->param_mean[j]);
+    for (int j = 0; j < 5; ++j) h.push_back(w->param_std[j]);
+    afiv_decoder *d = new (std::nothrow) afiv_decoder();
+    if (!d) return AFIV_E_HIP;
+    if (hipGetDevice(&d->device) != hipSuccess) { delete d; return AFIV_E_HIP; }
+    float *dev = nullptr;
+    if (hipMalloc((void **)&dev, h.size() * sizeof(float)) != hipSuccess) { delete d; return AFIV_E_HIP; }
+    if (hipMemcpy(dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev); delete d; return AFIV_E_HIP;
+    }
+    d->block = dev;
+    d->v.packed = dev;
+    d->v.pmean = dev + npacked;
+    d->v.pstd = dev + npacked + 5;
+    *out = d;
+    return AFIV_OK;
+}
+
+int afiv_decoder_destroy(afiv_decoder *d)
+{
+    if (!d) return AFIV_OK;
+    if (d->block) (void)hipFree(d->block);
+    delete d;
+    return AFIV_OK;
+}
+
+int afiv_decode(const afiv_decoder *d, const float *z, const float *c, int64_t N, int64_t c_rows,
+                float *normalized_out, float *params32_out, double *params64_out, void *stream)
+{
+    if (!d) return AFIV_E_NULL;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AFIV_E_HIP;
+    if (dev != d->device) return AFIV_E_ARG;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (N == 0) return AFIV_OK;
+    if (!z || !c) return AFIV_E_NULL;
+    if (c_rows != 1 && c_rows != N) return AFIV_E_SHAPE;
+    if (!normalized_out && !params32_out && !params64_out) return AFIV_E_NULL;
+    return afiv_launch_decode(d->v, z, c, N, c_rows, normalized_out, params32_out, params64_out,
+                              as_stream(stream));
+}
+
+int afiv_arbitrage_penalty(const afiv_grid *g, const double *params, int64_t B, double *scratch,
+                           double *acc_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (B < 0) return AFIV_E_SHAPE;
+    if (!acc_out) return AFIV_E_NULL;
+    if (B > 0 && (!params || !scratch)) return AFIV_E_NULL;
+    hipStream_t s = as_stream(stream);
+    if (B > 0 && (rc = afiv_launch_price(g->v, params, B, scratch, s))) return rc;
+    return afiv_launch_penalty(g->v, scratch, B, acc_out, s);
+}
+
+int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const double *params, int64_t C,
+                          const double *market_ratio, int64_t D, double drift_weight, double *loss_out,
+                          void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (C < 0 || D < 0) return AFIV_E_SHAPE;
+    if (C == 0 || D == 0) return AFIV_OK;
+    if (!model_ratio || !params || !market_ratio || !loss_out) return AFIV_E_NULL;
+    return afiv_launch_stage1(g->v, model_ratio, params, C, market_ratio, D, drift_weight, loss_out,
+                              as_stream(stream));
+}
+
+}  // extern "C"

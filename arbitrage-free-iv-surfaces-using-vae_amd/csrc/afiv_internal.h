@@ -1,0 +1,66 @@
+// Shared declarations between the translation units of libafiv.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "afiv.h"
+
+#define AFIV_NQ_NODES 144                 // Gauss-Laguerre nodes (QuantLib's default order)
+#define AFIV_KDIM (4 * AFIV_NQ_NODES)     // contraction length: 2 integrals x 144 nodes x (sin,cos)
+
+// Device view of a grid: everything that depends only on (logm, tau, r, q).  All pointers are
+// device memory owned by the afiv_grid.  Passed to kernels by value.
+struct GridView {
+    int nT, nK, nKpad;        // nKpad = nK rounded up to a multiple of 16 (MFMA column tiles)
+    double r, q;
+    const double *tau;        // [nT] maturities as given
+    const double *term;       // [nT] year fraction actually priced (floor(365 tau)/365 or tau)
+    const double *dd;         // [nT] -log(Dr/Dq)
+    const double *Dq;         // [nT] 1/exp(q*term)
+    const double *Dr;         // [nT] 1/exp(r*term)
+    const double *disc_tau;   // [nT] exp(-r*tau)
+    const double *fwd_mult;   // [nT] exp((r-q)*tau)
+    const double *dq_tau;     // [nT] exp(-q*tau)
+    const double *logm;       // [nK]
+    const double *Kmult;      // [nK] exp(logm)
+    const double *tab;        // [AFIV_KDIM][nKpad] strike tables, see afiv_price.hip
+};
+
+struct afiv_grid {
+    GridView v;
+    int device;
+    void *block;              // one allocation holding every array above
+    double *workspace;        // optional [workspace_surfaces][nT][nK]
+    int64_t workspace_surfaces;
+};
+
+struct DecoderView {
+    // One packed float array: for each hidden layer the weights stored input-major
+    // (w[i*OUT + o]), the bias, and the eval-mode BatchNorm as scale = gamma/sqrt(var+eps),
+    // shift = beta - mean*scale; then the output layer's weights and bias.
+    const float *packed;
+    const float *pmean, *pstd;
+};
+
+struct afiv_decoder {
+    DecoderView v;
+    int device;
+    void *block;
+};
+
+// Launchers implemented in the kernel translation units.
+int afiv_launch_price(const GridView &g, const double *params, int64_t N, double *ratio_out,
+                      hipStream_t s);
+int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, double spot,
+                            int variant, double *iv_out, hipStream_t s);
+int afiv_launch_arb_check(const GridView &g, const double *iv, const double *ratio, int64_t N,
+                          double spot, int bs_form, int32_t *flags_out, hipStream_t s);
+int afiv_launch_decode(const DecoderView &d, const float *z, const float *c, int64_t N,
+                       int64_t c_rows, float *normalized_out, float *p32, double *p64,
+                       hipStream_t s);
+int afiv_launch_penalty(const GridView &g, const double *ratio, int64_t B, double *acc_out,
+                        hipStream_t s);
+int afiv_launch_stage1(const GridView &g, const double *model_ratio, const double *params,
+                       int64_t C, const double *market_ratio, int64_t D, double drift_weight,
+                       double *loss_out, hipStream_t s);

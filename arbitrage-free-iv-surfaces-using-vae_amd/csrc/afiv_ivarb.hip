@@ -1,0 +1,369 @@
+// Implied-volatility inversion and arbitrage checks on gfx950.
+//
+// Compiled with -ffp-contract=off: these kernels reproduce NumPy/SciPy evaluation order so that
+// guards, bracket signs and violation counts agree with the Python reference bit for bit on
+// identical inputs (mul and add are never fused here).
+//
+//   implied vol : generate_iv_surface_by_date.py:296-318 (variant A) and
+//                 generate_regime_surfaces.py:138-177 (variant B); the root finder follows
+//                 scipy.optimize.brentq step for step (one lane per grid point), because
+//                 variant B's objective is not monotone and only the same iteration path
+//                 lands on the same root.
+//   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
+#include "afiv_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double ndtr_dev(double a)
+{
+    // scipy.special.ndtr branch structure (Cephes ndtr.c)
+    if (isnan(a)) return a;
+    const double sqrth = 7.07106781186547524401E-1;
+    const double x = a * sqrth;
+    const double z = fabs(x);
+    double y;
+    if (z < sqrth) {
+        y = 0.5 + 0.5 * erf(x);
+    } else {
+        y = 0.5 * erfc(z);
+        if (x > 0) y = 1.0 - y;
+    }
+    return y;
+}
+
+// Per-point constants of the Black-Scholes objective.
+struct BsPoint {
+    double lnFK;      // log(F/K)                       (variant A)
+    double F, K;      // spot*exp((r-q)tau), spot*exp(logm)
+    double disc;      // exp(-r tau)
+    double sdq;       // spot*exp(-q tau)               (variant B)
+    double kdr;       // K*exp(-r tau)                  (variant B)
+    double logm, rq;  // logm, r - q                    (variant B)
+    double tau, sqrt_tau;
+    double target;    // heston price
+};
+
+template <int VARIANT>
+__device__ __forceinline__ double bs_price(const BsPoint &c, double iv)
+{
+    if (VARIANT == AFIV_VARIANT_A) {
+        const double d1 = (c.lnFK + 0.5 * (iv * iv) * c.tau) / (iv * c.sqrt_tau);
+        const double d2 = d1 - iv * c.sqrt_tau;
+        return c.disc * (c.F * ndtr_dev(d1) - c.K * ndtr_dev(d2));
+    } else {
+        if (iv <= 0 || c.tau <= 0) return 1e10;
+        const double d1 = (c.logm + (c.rq + 0.5 * (iv * iv)) * c.tau) / (iv * c.sqrt_tau);
+        const double d2 = d1 - iv * c.sqrt_tau;
+        return c.sdq * ndtr_dev(d1) - c.kdr * ndtr_dev(d2);
+    }
+}
+
+// scipy/optimize/Zeros/brentq.c with the Python wrapper's NaN check; NaN on any failure.
+template <int VARIANT>
+__device__ double brentq_dev(const BsPoint &c, double xa, double xb, double xtol, double rtol, int maxiter)
+{
+    double xpre = xa, xcur = xb, xblk = 0.0, fpre, fcur, fblk = 0.0, spre = 0.0, scur = 0.0;
+    double sbis, delta, stry, dpre, dblk;
+    const double nan = __builtin_nan("");
+    fpre = bs_price<VARIANT>(c, xpre) - c.target;
+    if (isnan(fpre)) return nan;
+    fcur = bs_price<VARIANT>(c, xcur) - c.target;
+    if (isnan(fcur)) return nan;
+    if (fpre == 0) return xpre;
+    if (fcur == 0) return xcur;
+    if (signbit(fpre) == signbit(fcur)) return nan;
+    for (int i = 0; i < maxiter; ++i) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2;
+        sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
+            if (2 * fabs(stry) < lim) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else {
+            spre = sbis; scur = sbis;
+        }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = bs_price<VARIANT>(c, xcur) - c.target;
+        if (isnan(fcur)) return nan;
+    }
+    return nan;   // not converged: the reference's brentq raises -> NaN
+}
+
+__device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, double spot)
+{
+    BsPoint c;
+    c.tau = g.tau[t];
+    c.sqrt_tau = sqrt(c.tau);
+    c.disc = g.disc_tau[t];
+    c.K = spot * g.Kmult[k];
+    c.F = spot * g.fwd_mult[t];
+    c.lnFK = log(c.F / c.K);
+    c.sdq = spot * g.dq_tau[t];
+    c.kdr = c.K * c.disc;
+    c.logm = g.logm[k];
+    c.rq = g.r - g.q;
+    c.target = 0.0;
+    return c;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void implied_vol_kernel(GridView g, const double *__restrict__ ratio,
+                                                          int64_t total, double spot,
+                                                          double *__restrict__ iv_out)
+{
+    const int per = g.nT * g.nK;
+    const double nan = __builtin_nan("");
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int pt = (int)(i % per);
+        const int t = pt / g.nK, k = pt - t * g.nK;
+        const double pr = ratio[i];
+        BsPoint c = make_point(g, t, k, spot);
+        const double hp = pr * spot * c.disc;
+        c.target = hp;
+        double iv;
+        if (VARIANT == AFIV_VARIANT_A) {
+            const double intrinsic = fmax(c.F - c.K, 0.0) * c.disc;
+            if (hp < intrinsic * 0.99) iv = nan;
+            else iv = brentq_dev<VARIANT>(c, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+        } else {
+            if (hp < 1e-10 || isnan(pr)) iv = nan;
+            else {
+                iv = brentq_dev<VARIANT>(c, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+                if (isnan(iv) || iv <= 0 || iv > 3.0) iv = nan;
+            }
+        }
+        iv_out[i] = iv;
+    }
+}
+
+// One workgroup per surface.
+constexpr int ARB_THREADS = 256;
+constexpr int MAX_PTS = AFIV_MAX_STRIKES * AFIV_MAX_MATURITIES;
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int BSFORM>
+__global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const double *__restrict__ iv,
+                                                          const double *__restrict__ ratio, int64_t N,
+                                                          double spot, int32_t *__restrict__ flags)
+{
+    __shared__ double price[MAX_PTS];
+    __shared__ int skip_t[AFIV_MAX_MATURITIES];
+    __shared__ int counters[5];      // nan, invalid, static, calendar, butterfly
+    const int nT = g.nT, nK = g.nK, per = nT * nK;
+    const int tid = threadIdx.x;
+    for (int64_t s = blockIdx.x; s < N; s += gridDim.x) {
+        if (tid < 5) counters[tid] = 0;
+        if (tid < AFIV_MAX_MATURITIES) skip_t[tid] = 0;
+        __syncthreads();
+        const double *v = iv + s * per;
+        const double *pr = ratio ? ratio + s * per : nullptr;
+        int n_nan = 0, n_bad = 0;
+        for (int i = tid; i < per; i += ARB_THREADS) {
+            const int t = i / nK, k = i - t * nK;
+            const double x = v[i];
+            if (isnan(x)) { n_nan++; n_bad++; }
+            else if (x <= 0) n_bad++;
+            BsPoint c = make_point(g, t, k, spot);
+            price[i] = bs_price<BSFORM>(c, x);
+            if (pr) {
+                const double y = pr[i];
+                if (isnan(y) || y < 0) skip_t[t] = 1;      // benign race: all writers store 1
+            }
+        }
+        n_nan = wave_sum(n_nan);
+        n_bad = wave_sum(n_bad);
+        if ((tid & 63) == 0) {
+            if (n_nan) atomicAdd(&counters[0], n_nan);
+            if (n_bad) atomicAdd(&counters[1], n_bad);
+        }
+        __syncthreads();
+        int n_stat = 0, n_cal = 0, n_fly = 0;
+        const bool valid = counters[1] == 0;
+        for (int i = tid; i < per; i += ARB_THREADS) {
+            const int t = i / nK, k = i - t * nK;
+            if (valid) {
+                if (k + 1 < nK && price[i] < price[i + 1] - 1e-6) n_stat++;
+                if (t + 1 < nT && price[i] > price[i + nK] + 1e-6) n_cal++;
+            }
+            if (pr && k + 2 < nK && !skip_t[t]) {
+                const double b = pr[i] - 2 * pr[i + 1] + pr[i + 2];
+                if (b < 0) n_fly++;
+            }
+        }
+        n_stat = wave_sum(n_stat);
+        n_cal = wave_sum(n_cal);
+        n_fly = wave_sum(n_fly);
+        if ((tid & 63) == 0) {
+            if (n_stat) atomicAdd(&counters[2], n_stat);
+            if (n_cal) atomicAdd(&counters[3], n_cal);
+            if (n_fly) atomicAdd(&counters[4], n_fly);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int nn = counters[0];
+            const int st = valid ? counters[2] : -1;
+            const int ca = valid ? counters[3] : -1;
+            const int fl = counters[4];
+            int status = 0;
+            if (valid && st == 0 && ca == 0) status |= 1;
+            if (fl == 0) status |= 2;
+            if (valid) status |= 4;
+            if ((double)nn / (double)per < 0.1) status |= 8;
+            if (nn == 0) status |= 16;
+            flags[4 * s + 0] = st;
+            flags[4 * s + 1] = ca;
+            flags[4 * s + 2] = fl;
+            flags[4 * s + 3] = status;
+        }
+        __syncthreads();
+    }
+}
+
+// cvae_model.py:272-285 over a batch: sum and count of the collected penalties.
+// Single workgroup, fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void penalty_kernel(GridView g, const double *__restrict__ ratio,
+                                                      int64_t B, double *__restrict__ acc_out)
+{
+    __shared__ double ssum[256];
+    __shared__ double scnt[256];
+    const int nT = g.nT, nK = g.nK;
+    double sum = 0.0, cnt = 0.0;
+    for (int64_t item = threadIdx.x; item < B * nT; item += 256) {
+        const double *pr = ratio + item * nK;
+        bool skip = false;
+        for (int k = 0; k < nK; ++k)
+            if (isnan(pr[k]) || pr[k] < 0) skip = true;
+        if (skip) continue;
+        for (int j = 0; j + 1 < nK; ++j)
+            if (pr[j + 1] > pr[j]) { sum += (pr[j + 1] - pr[j]) * 100.0; cnt += 1.0; }
+        for (int j = 0; j + 2 < nK; ++j) {
+            const double b = pr[j] - 2 * pr[j + 1] + pr[j + 2];
+            if (b < 0) { sum += -b * 100.0; cnt += 1.0; }
+        }
+    }
+    ssum[threadIdx.x] = sum;
+    scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + off];
+            scnt[threadIdx.x] += scnt[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { acc_out[0] = ssum[0]; acc_out[1] = scnt[0]; }
+}
+
+// run_single_heston_calibration.py:252-287 for (candidate c, day d).  One workgroup per
+// candidate keeps that candidate's model ratios in LDS; threads walk the days.
+__global__ __launch_bounds__(256) void stage1_kernel(GridView g, const double *__restrict__ model_ratio,
+                                                     const double *__restrict__ params, int64_t C,
+                                                     const double *__restrict__ market_ratio, int64_t D,
+                                                     double drift_weight, double *__restrict__ loss_out)
+{
+    __shared__ double model[MAX_PTS];
+    __shared__ int atm[MAX_PTS / AFIV_MAX_MATURITIES];
+    const int nT = g.nT, nK = g.nK, per = nT * nK;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += 256) model[i] = model_ratio[c * per + i];
+        for (int k = threadIdx.x; k < nK; k += 256) atm[k] = fabs(g.logm[k]) < 0.05 ? 1 : 0;
+        __syncthreads();
+        const double kappa = params[5 * c + 0], theta = params[5 * c + 1], sigma = params[5 * c + 2];
+        const double feller = 5.0 * fmax(0.0, sigma * sigma - 2 * kappa * theta);
+        for (int64_t d = threadIdx.x; d < D; d += 256) {
+            const double *mk = market_ratio + d * per;
+            double se = 0.0, sm_model = 0.0, sm_mkt = 0.0;
+            int n = 0, n_atm = 0;
+            bool bad = false;
+            for (int i = 0; i < per; ++i) {
+                const double y = mk[i];
+                if (isnan(y)) continue;
+                const double m = model[i];
+                if (isnan(m) || m < 0) bad = true;
+                const double e = m - y;
+                se += e * e;
+                n++;
+                if (atm[i % nK]) { sm_model += m; sm_mkt += y; n_atm++; }
+            }
+            double loss;
+            if (n < 10) loss = __builtin_nan("");          // the reference skips such a day (:202-203)
+            else if (bad) loss = 1e10;
+            else {
+                const double rmse = sqrt(se / n);
+                const double drift = n_atm > 0 ? fabs(sm_model / n_atm - sm_mkt / n_atm) : 0.0;
+                loss = rmse + drift_weight * drift + feller;
+            }
+            loss_out[c * D + d] = loss;
+        }
+    }
+}
+
+}  // namespace
+
+int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
+                            double *iv_out, hipStream_t s)
+{
+    if (N <= 0) return 0;
+    const int64_t total = N * g.nT * g.nK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (variant == 0)
+        hipLaunchKernelGGL(implied_vol_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, g, ratio, total, spot, iv_out);
+    else
+        hipLaunchKernelGGL(implied_vol_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, g, ratio, total, spot, iv_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int afiv_launch_arb_check(const GridView &g, const double *iv, const double *ratio, int64_t N, double spot,
+                          int bs_form, int32_t *flags_out, hipStream_t s)
+{
+    if (N <= 0) return 0;
+    int64_t blocks = N < 256 * 32 ? N : 256 * 32;
+    if (bs_form == 0)
+        hipLaunchKernelGGL(arb_kernel<0>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out);
+    else
+        hipLaunchKernelGGL(arb_kernel<1>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int afiv_launch_penalty(const GridView &g, const double *ratio, int64_t B, double *acc_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(penalty_kernel, dim3(1), dim3(256), 0, s, g, ratio, B, acc_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int afiv_launch_stage1(const GridView &g, const double *model_ratio, const double *params, int64_t C,
+                       const double *market_ratio, int64_t D, double drift_weight, double *loss_out,
+                       hipStream_t s)
+{
+    if (C <= 0 || D <= 0) return 0;
+    int64_t blocks = C < 256 * 16 ? C : 256 * 16;
+    hipLaunchKernelGGL(stage1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, model_ratio, params, C,
+                       market_ratio, D, drift_weight, loss_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,147 @@
+/*
+ * afiv -- MI355X (gfx950) kernels for arbitrage-checked Heston implied-volatility surfaces.
+ *
+ * C ABI of libafiv.so.  The reference project is pure Python with no FFI of its own, so each
+ * entry point below names the Python routine whose arithmetic it replaces; the Python drop-in
+ * modules bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - "host" pointers are ordinary CPU memory and are only read during the call.
+ *   - "device" pointers are HIP device memory owned by the caller (for example the data_ptr()
+ *     of a torch tensor on the current device).  Execution entry points enqueue work on
+ *     `stream` (a hipStream_t passed as void*, NULL = the default stream) and return without
+ *     synchronising; they allocate nothing.
+ *   - Return value 0 = success, negative = AFIV_E_* below.  Per-point numerical failures are
+ *     data (NaN implied vols, flag words), never errors, as in the reference's try/except -> NaN
+ *     (generate_iv_surface_by_date.py:316-318).
+ *   - All arrays are dense, row-major, in the shapes written next to each argument.
+ */
+#ifndef AFIV_H
+#define AFIV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFIV_VERSION 100
+
+enum {
+    AFIV_OK = 0,
+    AFIV_E_NULL = -1,        /* required pointer is NULL */
+    AFIV_E_SHAPE = -2,       /* a size is out of the supported range */
+    AFIV_E_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+    AFIV_E_ARG = -4,         /* bad enum / flag value */
+    AFIV_E_WORKSPACE = -5    /* the call needs a workspace the grid was created without */
+};
+
+/* Which Black-Scholes form is inverted / re-priced. */
+enum {
+    AFIV_VARIANT_A = 0,  /* forward form, generate_iv_surface_by_date.py:308-312 */
+    AFIV_VARIANT_B = 1   /* spot form as written in generate_regime_surfaces.py:154-159 */
+};
+
+/* Limits of this build. */
+#define AFIV_MAX_STRIKES 64      /* strikes per grid */
+#define AFIV_MAX_MATURITIES 64   /* maturities per grid */
+
+typedef struct afiv_grid afiv_grid;
+typedef struct afiv_decoder afiv_decoder;
+
+int afiv_version(void);
+const char *afiv_error_string(int code);
+
+/* ---- grid: the (maturity, strike) lattice and everything that depends only on it ----------
+ * Replaces the per-call constants of heston_model_ql.py:109-179: strike = exp(logm) (:171),
+ * maturity date = evaluation date + int(tau*365) days under Actual/365F (:131; pass
+ * trunc_days = 1 for that behaviour, 0 to price at tau itself), flat-forward discount factors
+ * for r and q (:60-69) and the untruncated discount exp(-r*tau) of :176.  Also holds the
+ * strike-dependent cos/sin tables of the 144-node Gauss-Laguerre rule.
+ * logm_host[nK], tau_host[nT] are host arrays.  workspace_surfaces > 0 reserves device memory
+ * for that many surfaces' price ratios so afiv_surface may be called with ratio_out == NULL.
+ * Must be called with the target device current; the grid is bound to that device. */
+int afiv_grid_create(afiv_grid **out, const double *logm_host, int nK, const double *tau_host,
+                     int nT, double r, double q, int trunc_days, int64_t workspace_surfaces);
+int afiv_grid_destroy(afiv_grid *g);
+
+/* ---- pricing: replaces HestonModelQL.price_ratio (heston_model_ql.py:151-179) evaluated over
+ * the whole grid, i.e. QuantLib AnalyticHestonEngine(model) (:87) per option.
+ * params: device [N,5] doubles (kappa, theta, sigma_v, rho, v0); ratio_out: device [N,nT,nK]. */
+int afiv_price(const afiv_grid *g, const double *params, int64_t N, double *ratio_out,
+               void *stream);
+
+/* ---- implied volatility: replaces the inner loop body of generate_iv_surface
+ * (generate_iv_surface_by_date.py:296-318 for AFIV_VARIANT_A, generate_regime_surfaces.py:138-177
+ * for AFIV_VARIANT_B): guard, then Brent's method on [0.001, 3.0] with xtol 1e-6 as
+ * scipy.optimize.brentq runs it; NaN where the reference yields NaN.
+ * ratio: device [N,nT,nK]; iv_out: device [N,nT,nK]. */
+int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double spot,
+                     int variant, double *iv_out, void *stream);
+
+/* ---- arbitrage checks: replaces check_static_arbitrage / check_calendar_arbitrage /
+ * check_all_arbitrage (generate_regime_surfaces.py:188-283) and the static + butterfly rule of
+ * compute_arbitrage_penalty (cvae_model.py:272-285) applied to every strike triple.
+ * iv: device [N,nT,nK]; ratio: device [N,nT,nK] or NULL (then butterfly count = 0);
+ * flags_out: device [N,4] int32 = { static_violations, calendar_violations,
+ * butterfly_violations, status }.  static/calendar are -1 when the surface holds a NaN or
+ * non-positive IV (the reference returns None).  status bits: 1 = arbitrage-free as
+ * generate_regime_surfaces.py:282; 2 = no butterfly violation; 4 = surface valid;
+ * 8 = success as generate_iv_surface_by_date.py:321 (NaN share < 10 %); 16 = no NaN at all
+ * (generate_regime_surfaces.py:180).  bs_form selects the re-pricing formula (AFIV_VARIANT_*). */
+int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, int64_t N,
+                   double spot, int bs_form, int32_t *flags_out, void *stream);
+
+/* ---- whole surface: price -> implied vol -> checks for N parameter sets, i.e. the body of the
+ * per-sample loop generate_iv_surface_by_date.py:464-468 plus the checks above.
+ * ratio_out may be NULL if the grid has a workspace (the batch is then processed in
+ * workspace-sized chunks); iv_out and flags_out are required. */
+int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
+                 double *ratio_out, double *iv_out, int32_t *flags_out, void *stream);
+
+/* ---- decoder: replaces ConditionalVAE_SingleHeston.decode (cvae_model.py:145-160, decoder
+ * stack :84-105 in eval mode) followed by the de-normalisation and exp/tanh transforms of
+ * generate_iv_surface_by_date.py:441-446.  Host arrays follow the checkpoint's state-dict
+ * layout: linear weights [out,in] row-major, BatchNorm weight/bias/running_mean/running_var. */
+typedef struct afiv_decoder_weights {
+    const float *lin_w[4];   /* decoder.0/4/8/12.weight : [32,12] [64,32] [128,64] [5,128] */
+    const float *lin_b[4];   /* decoder.0/4/8/12.bias */
+    const float *bn_w[3];    /* decoder.1/5/9.weight */
+    const float *bn_b[3];    /* decoder.1/5/9.bias */
+    const float *bn_mean[3]; /* decoder.1/5/9.running_mean */
+    const float *bn_var[3];  /* decoder.1/5/9.running_var */
+    const float *param_mean; /* [5] */
+    const float *param_std;  /* [5] */
+    float bn_eps;            /* 1e-5 */
+} afiv_decoder_weights;
+
+int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w_host);
+int afiv_decoder_destroy(afiv_decoder *d);
+
+/* z: device [N,4] float; c: device [c_rows,8] float with c_rows == N or 1 (one row broadcast,
+ * as cvae_model.py:365-366).  Outputs (either may be NULL): normalized_out [N,5] float = raw
+ * decoder output; params32_out [N,5] float = transformed parameters; params64_out [N,5] double =
+ * the same values widened (what generate_iv_surface receives, :286). */
+int afiv_decode(const afiv_decoder *d, const float *z, const float *c, int64_t N, int64_t c_rows,
+                float *normalized_out, float *params32_out, double *params64_out, void *stream);
+
+/* ---- training-time arbitrage penalty: replaces compute_arbitrage_penalty
+ * (cvae_model.py:208-298).  params: device [B,5] doubles, already de-normalised and
+ * transformed; g must be the 5-strike x 2-maturity grid of cvae_model.py:245-246 (any grid
+ * works: the rule is applied per maturity).  scratch: device [B*nT*nK] doubles;
+ * acc_out: device [2] doubles = { sum of penalties, number of penalties }. */
+int afiv_arbitrage_penalty(const afiv_grid *g, const double *params, int64_t B, double *scratch,
+                           double *acc_out, void *stream);
+
+/* ---- calibration Stage-1 objective: replaces objective_stage1
+ * (run_single_heston_calibration.py:252-287) for C candidate parameter sets against D days.
+ * model_ratio: device [C,nT,nK] (from afiv_price); market_ratio: device [D,nT,nK] (NaN marks
+ * points the reference drops at :185); params: device [C,5]; loss_out: device [C,D]. */
+int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const double *params,
+                          int64_t C, const double *market_ratio, int64_t D, double drift_weight,
+                          double *loss_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFIV_H */
