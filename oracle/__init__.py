@@ -70,8 +70,18 @@ def lib() -> ctypes.CDLL:
         L.afo_arbitrage_penalty.restype = None
         L.afo_arbitrage_penalty.argtypes = [_dp, ctypes.c_long, ctypes.c_double, ctypes.c_double,
                                             _dp, ctypes.POINTER(ctypes.c_long)]
+        L.afo_set_threads.restype = None
+        L.afo_set_threads.argtypes = [ctypes.c_int]
+        L.afo_max_threads.restype = ctypes.c_int
+        L.afo_max_threads.argtypes = []
         _LIB = L
     return _LIB
+
+
+def set_threads(n: int) -> int:
+    """Set the OpenMP thread count of the batch functions; returns the count in effect."""
+    lib().afo_set_threads(int(n))
+    return lib().afo_max_threads()
 
 
 def _c(a):

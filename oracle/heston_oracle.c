@@ -405,3 +405,13 @@ void afo_arbitrage_penalty(const double *params, long n, double r, double q,
 }
 
 int afo_num_nodes(void) { return AFIV_NQ; }
+
+/* Thread control for the timed CPU baseline (OpenMP over surfaces). */
+#ifdef _OPENMP
+#include <omp.h>
+void afo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int afo_max_threads(void) { return omp_get_max_threads(); }
+#else
+void afo_set_threads(int n) { (void)n; }
+int afo_max_threads(void) { return 1; }
+#endif
