@@ -41,7 +41,7 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     pad_shape = (longest,) + tuple(local.shape[1:])
     buf = local.new_zeros(pad_shape)
     buf[: local.shape[0]] = local
-    out = local.new_empty((world,) + pad_shape)
+    out = local.new_empty((world * longest,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
-    parts = [out[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)]
+    parts = [out[r * longest: r * longest + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
