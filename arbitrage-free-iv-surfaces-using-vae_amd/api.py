@@ -121,17 +121,20 @@ class Grid:
         return out
 
     def arb_check(self, iv: torch.Tensor, ratio: torch.Tensor | None, spot: float,
-                  bs_form="A") -> torch.Tensor:
-        """Flags [N,4] int32 = (static, calendar, butterfly, status)."""
+                  bs_form="A", want_mask: bool = False):
+        """Flags [N,4] int32 = (static, calendar, butterfly, status); with ``want_mask`` also the
+        [N,nT,nK] uint8 violation mask (bit 1 static, 2 calendar, 4 butterfly)."""
         v = self._lattice(iv, "iv")
         ra = None if ratio is None else self._lattice(ratio, "ratio")
         n = v.shape[0]
         flags = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        mask = torch.empty((n, self.nT, self.nK), dtype=torch.uint8, device=self.device) \
+            if want_mask else None
         with torch.cuda.device(self.device):
             rc = _lib.lib().afiv_arb_check(self._h, _ptr(v), _ptr(ra), n, float(spot),
-                                           VARIANTS[bs_form], _ptr(flags), _stream())
+                                           VARIANTS[bs_form], _ptr(flags), _ptr(mask), _stream())
         _lib.check(rc, "afiv_arb_check")
-        return flags
+        return (flags, mask) if want_mask else flags
 
     def surface(self, params: torch.Tensor, spot: float, variant="A", keep_ratio: bool = True,
                 iv_out: torch.Tensor | None = None, flags_out: torch.Tensor | None = None,

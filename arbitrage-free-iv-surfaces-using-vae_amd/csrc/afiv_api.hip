@@ -150,7 +150,7 @@ int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double 
 }
 
 int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, int64_t N, double spot,
-                   int bs_form, int32_t *flags_out, void *stream)
+                   int bs_form, int32_t *flags_out, uint8_t *mask_out, void *stream)
 {
     int rc = check_grid(g);
     if (rc) return rc;
@@ -158,7 +158,7 @@ int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, in
     if (bs_form != AFIV_VARIANT_A && bs_form != AFIV_VARIANT_B) return AFIV_E_ARG;
     if (N == 0) return AFIV_OK;
     if (!iv || !flags_out) return AFIV_E_NULL;
-    return afiv_launch_arb_check(g->v, iv, ratio, N, spot, bs_form, flags_out, as_stream(stream));
+    return afiv_launch_arb_check(g->v, iv, ratio, N, spot, bs_form, flags_out, mask_out, as_stream(stream));
 }
 
 int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
@@ -175,7 +175,7 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
     if (ratio_out) {
         if ((rc = afiv_launch_price(g->v, params, N, ratio_out, s))) return rc;
         if ((rc = afiv_launch_implied_vol(g->v, ratio_out, N, spot, variant, iv_out, s))) return rc;
-        return afiv_launch_arb_check(g->v, iv_out, ratio_out, N, spot, variant, flags_out, s);
+        return afiv_launch_arb_check(g->v, iv_out, ratio_out, N, spot, variant, flags_out, nullptr, s);
     }
     if (!g->workspace) return AFIV_E_WORKSPACE;
     // Stream order makes the reuse of the workspace by consecutive chunks safe.
@@ -184,7 +184,7 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
         if ((rc = afiv_launch_price(g->v, params + 5 * off, n, g->workspace, s))) return rc;
         if ((rc = afiv_launch_implied_vol(g->v, g->workspace, n, spot, variant, iv_out + off * per, s))) return rc;
         if ((rc = afiv_launch_arb_check(g->v, iv_out + off * per, g->workspace, n, spot, variant,
-                                        flags_out + 4 * off, s))) return rc;
+                                        flags_out + 4 * off, nullptr, s))) return rc;
     }
     return AFIV_OK;
 }

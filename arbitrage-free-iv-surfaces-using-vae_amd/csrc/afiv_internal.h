@@ -55,7 +55,7 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
 int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, double spot,
                             int variant, double *iv_out, hipStream_t s);
 int afiv_launch_arb_check(const GridView &g, const double *iv, const double *ratio, int64_t N,
-                          double spot, int bs_form, int32_t *flags_out, hipStream_t s);
+                          double spot, int bs_form, int32_t *flags_out, uint8_t *mask_out, hipStream_t s);
 int afiv_launch_decode(const DecoderView &d, const float *z, const float *c, int64_t N,
                        int64_t c_rows, float *normalized_out, float *p32, double *p64,
                        hipStream_t s);

@@ -168,7 +168,8 @@ __device__ __forceinline__ int wave_sum(int v)
 template <int BSFORM>
 __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const double *__restrict__ iv,
                                                           const double *__restrict__ ratio, int64_t N,
-                                                          double spot, int32_t *__restrict__ flags)
+                                                          double spot, int32_t *__restrict__ flags,
+                                                          uint8_t *__restrict__ mask)
 {
     __shared__ double price[MAX_PTS];
     __shared__ int skip_t[AFIV_MAX_MATURITIES];
@@ -205,14 +206,16 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
         const bool valid = counters[1] == 0;
         for (int i = tid; i < per; i += ARB_THREADS) {
             const int t = i / nK, k = i - t * nK;
+            unsigned m = 0;
             if (valid) {
-                if (k + 1 < nK && price[i] < price[i + 1] - 1e-6) n_stat++;
-                if (t + 1 < nT && price[i] > price[i + nK] + 1e-6) n_cal++;
+                if (k + 1 < nK && price[i] < price[i + 1] - 1e-6) { n_stat++; m |= 1u; }
+                if (t + 1 < nT && price[i] > price[i + nK] + 1e-6) { n_cal++; m |= 2u; }
             }
             if (pr && k + 2 < nK && !skip_t[t]) {
                 const double b = pr[i] - 2 * pr[i + 1] + pr[i + 2];
-                if (b < 0) n_fly++;
+                if (b < 0) { n_fly++; m |= 4u; }
             }
+            if (mask) mask[s * per + i] = (uint8_t)m;
         }
         n_stat = wave_sum(n_stat);
         n_cal = wave_sum(n_cal);
@@ -340,14 +343,14 @@ int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, d
 }
 
 int afiv_launch_arb_check(const GridView &g, const double *iv, const double *ratio, int64_t N, double spot,
-                          int bs_form, int32_t *flags_out, hipStream_t s)
+                          int bs_form, int32_t *flags_out, uint8_t *mask_out, hipStream_t s)
 {
     if (N <= 0) return 0;
     int64_t blocks = N < 256 * 32 ? N : 256 * 32;
     if (bs_form == 0)
-        hipLaunchKernelGGL(arb_kernel<0>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out);
+        hipLaunchKernelGGL(arb_kernel<0>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out, mask_out);
     else
-        hipLaunchKernelGGL(arb_kernel<1>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out);
+        hipLaunchKernelGGL(arb_kernel<1>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out, mask_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

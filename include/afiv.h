@@ -88,9 +88,13 @@ int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double 
  * non-positive IV (the reference returns None).  status bits: 1 = arbitrage-free as
  * generate_regime_surfaces.py:282; 2 = no butterfly violation; 4 = surface valid;
  * 8 = success as generate_iv_surface_by_date.py:321 (NaN share < 10 %); 16 = no NaN at all
- * (generate_regime_surfaces.py:180).  bs_form selects the re-pricing formula (AFIV_VARIANT_*). */
+ * (generate_regime_surfaces.py:180).  bs_form selects the re-pricing formula (AFIV_VARIANT_*).
+ * mask_out: NULL, or device [N,nT,nK] bytes receiving where the violations sit, i.e. the
+ * (mat_idx, strike_idx) lists the reference functions return: bit 1 = static violation between
+ * strikes k and k+1, bit 2 = calendar violation between maturities t and t+1, bit 4 = negative
+ * butterfly on strikes k..k+2.  Static/calendar bits are only set on valid surfaces. */
 int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, int64_t N,
-                   double spot, int bs_form, int32_t *flags_out, void *stream);
+                   double spot, int bs_form, int32_t *flags_out, uint8_t *mask_out, void *stream);
 
 /* ---- whole surface: price -> implied vol -> checks for N parameter sets, i.e. the body of the
  * per-sample loop generate_iv_surface_by_date.py:464-468 plus the checks above.

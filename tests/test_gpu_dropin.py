@@ -1,0 +1,207 @@
+"""GPU tests of the drop-in modules: same import names and call signatures as the reference's
+heston_model_ql / cvae_model / generate_iv_surface_by_date / generate_regime_surfaces, checked
+against the oracle and the golden vectors."""
+import importlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import afiv_bootstrap
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+T_GRID = np.array([0.08333333, 0.16666667, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+LOGM_GRID = np.linspace(-0.2, 0.2, 21)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    for p in afiv_bootstrap.dropin_paths():
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    names = ("heston_model_ql", "cvae_model", "generate_iv_surface_by_date", "generate_regime_surfaces")
+    return {n: importlib.import_module(n) for n in names}
+
+
+def test_heston_model_scalar_and_array_calls(mods):
+    H = mods["heston_model_ql"].HestonModelQL
+    m = H(2.0, 0.09, 0.3, -0.7, 0.09)                       # the reference's own smoke-test model
+    assert m.spot == 1.0 and m.r == 0.067 and m.q == 0.0
+    assert m.check_feller_condition() == (2 * 2.0 * 0.09 > 0.3 ** 2)
+    p = [2.0, 0.09, 0.3, -0.7, 0.09]
+    a = m.price_ratio(0.02, 0.5)
+    assert isinstance(a, float)
+    assert abs(a - oracle.price_ratio(p, 0.02, 0.5)) <= 1e-8 * max(a, 1e-4)
+    arr = m.price_ratio(LOGM_GRID, 0.25)
+    ref = oracle.price_ratio_grid(p, LOGM_GRID, [0.25])[0, 0]
+    assert arr.shape == (21,) and np.all(np.abs(arr - ref) <= 1e-8 * np.maximum(ref, 1e-4))
+    # price_call ignores S and works on strikes (heston_model_ql.py:109-149)
+    c1 = m.price_call(1.0, np.exp(LOGM_GRID), 0.25)
+    c2 = m.price_call(12345.0, np.exp(LOGM_GRID), 0.25)
+    assert np.array_equal(c1, c2)
+    assert np.all(np.abs(c1 - ref * np.exp(-0.067 * 0.25)) <= 1e-12)
+    assert isinstance(m.price_call(1.0, 1.02, 0.5), float)
+    m.update_parameters(1.0, 0.04, 0.5, -0.5, 0.04)
+    b = m.price_ratio(0.0, 1.0)
+    assert abs(b - oracle.price_ratio([1.0, 0.04, 0.5, -0.5, 0.04], 0.0, 1.0)) <= 1e-9
+    assert mods["heston_model_ql"].HestonModel is H
+
+
+def test_time_varying_wrapper(mods):
+    TV = mods["heston_model_ql"].TimeVaryingHestonModelQL
+    plist = [dict(kappa=2.0, theta=0.05, sigma_v=0.3, rho=-0.6, v0=0.04),
+             dict(kappa=1.0, theta=0.06, sigma_v=0.4, rho=-0.5, v0=0.05)]
+    tv = TV([0.5, 1.0], plist)
+    lm = np.tile(np.linspace(-0.1, 0.1, 5), (2, 1))
+    out = tv.price_surface(lm)
+    for i, p in enumerate(plist):
+        ref = oracle.price_ratio_grid([p["kappa"], p["theta"], p["sigma_v"], p["rho"], p["v0"]],
+                                      lm[i], [[0.5, 1.0][i]])[0, 0]
+        assert np.all(np.abs(out[i] - ref) <= 1e-9)
+    assert len(tv.check_all_feller_conditions()) == 2
+
+
+def _load_model(mods, golden_dir):
+    d = np.load(f"{golden_dir}/decoder.npz")
+    model = mods["cvae_model"].ConditionalVAE_SingleHeston()
+    sd = model.state_dict()
+    for k in d.files:
+        if k.startswith("decoder."):
+            assert k in sd, k
+            sd[k] = torch.tensor(d[k])
+    model.load_state_dict(sd)
+    return model.cuda().eval(), d
+
+
+def test_cvae_state_dict_layout_and_hip_decode(mods, golden_dir):
+    model, d = _load_model(mods, golden_dir)
+    keys = set(model.state_dict())
+    for k in ("encoder.0.weight", "encoder.9.running_var", "fc_mu.weight", "fc_logvar.bias",
+              "decoder.0.weight", "decoder.5.num_batches_tracked", "decoder.12.bias"):
+        assert k in keys
+    g = np.load(f"{golden_dir}/golden_decode.npz")
+    z = torch.tensor(g["z"]).cuda()
+    c = torch.tensor(g["c"]).cuda()
+    with torch.no_grad():
+        out = model.decode(z, c)
+        ref_torch = model.decoder(torch.cat([z, c], dim=1))
+    assert out.shape == (256, 5) and out.dtype == torch.float32
+    assert np.all(np.abs(out.cpu().numpy() - g["normalized"]) <= 2e-5 * np.maximum(1, np.abs(g["normalized"])))
+    assert torch.allclose(out, ref_torch, atol=3e-5, rtol=3e-5)
+    with torch.no_grad():
+        s = model.sample(50, c[:1], device="cuda")
+    assert s.shape == (50, 5)
+    # training mode keeps the differentiable torch path
+    model.train()
+    y = model.decode(z[:8], c[:8])
+    assert y.requires_grad
+    model.eval()
+    with pytest.raises(RuntimeError, match="CUDA"):
+        with torch.no_grad():
+            model.decode(z.cpu(), c.cpu())
+
+
+def test_cvae_arbitrage_penalty_and_loss(mods, golden_dir):
+    model, d = _load_model(mods, golden_dir)
+    g = np.load(f"{golden_dir}/golden_decode.npz")
+    mean = torch.tensor(d["param_mean"]).cuda()
+    std = torch.tensor(d["param_std"]).cuda()
+    norm = torch.tensor(g["normalized"][:64]).cuda()
+    pen = model.compute_arbitrage_penalty(norm, mean, std)
+    assert pen.dtype == torch.float32 and pen.device.type == "cuda" and pen.dim() == 0
+    ref = oracle.arbitrage_penalty(g["params"][:64].astype(np.float64))
+    assert abs(float(pen) - ref) <= 1e-6 * max(1.0, abs(ref))
+    fel = model.compute_feller_penalty(norm, mean, std)
+    p = g["params"][:64].astype(np.float64)
+    assert abs(float(fel) - np.maximum(p[:, 2] ** 2 - 2 * p[:, 0] * p[:, 1], 0).mean()) < 1e-5
+    # loss recomposition, as the reference's own smoke script asserts (test_setup.py:171-177)
+    model.train()
+    x = norm
+    c = torch.tensor(g["c"][:64]).cuda()
+    recon, mu, logvar = model(x, c)
+    total, rl, kl, fl, al = model.loss_function(recon, x, mu, logvar, mean, std)
+    manual = rl + model.beta * kl + model.feller_penalty_weight * fl + model.arbitrage_penalty_weight * al
+    assert abs(float(total) - float(manual)) < 1e-4
+    total.backward()
+
+
+def test_generate_iv_surface_signature_and_values(mods):
+    G = mods["generate_iv_surface_by_date"]
+    assert np.array_equal(G.T_GRID, T_GRID) and np.array_equal(G.LOGM_GRID, LOGM_GRID)
+    params = np.array([1.2, 0.04, 0.5, -0.6, 0.05], dtype=np.float32)
+    iv, ok = G.generate_iv_surface(params, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)
+    assert iv.shape == (8, 21) and isinstance(ok, bool)
+    p64 = params.astype(np.float64)[None]
+    ratio = oracle.price_ratio_grid(p64, LOGM_GRID, T_GRID)
+    ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, 21000.0, 0.067, 0.0, "A")[0]
+    assert np.mean(np.isnan(iv) == np.isnan(ref)) > 0.99
+    m = ~np.isnan(iv) & ~np.isnan(ref)
+    assert np.median(np.abs(iv[m] - ref[m])) <= 1e-9
+    assert ok == (np.isnan(ref).mean() < 0.1)
+    assert G.generate_iv_surface(["x"] * 5, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0) == (None, False)
+    ivs, oks = G.generate_iv_surfaces(np.tile(params, (5, 1)), G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)
+    assert ivs.shape == (5, 8, 21) and oks.shape == (5,)
+    assert np.array_equal(np.nan_to_num(ivs[3], nan=-1), np.nan_to_num(iv, nan=-1))
+
+
+def test_cli_offline_run_writes_reference_outputs(mods, golden_dir, tmp_path, capsys):
+    G = mods["generate_iv_surface_by_date"]
+    d = np.load(f"{golden_dir}/decoder.npz")
+    model = mods["cvae_model"].ConditionalVAE_SingleHeston()
+    sd = model.state_dict()
+    for k in d.files:
+        if k.startswith("decoder."):
+            sd[k] = torch.tensor(d[k])
+    ckpt = tmp_path / "cvae_model.pt"
+    torch.save({"model_state_dict": sd, "param_mean": torch.tensor(d["param_mean"]),
+                "param_std": torch.tensor(d["param_std"])}, ckpt)
+    csv = tmp_path / "cond.csv"
+    with open(csv, "w") as fh:
+        fh.write("date," + ",".join(d["cond_names"]) + "\n")
+        for date, row in zip(d["cond_dates"][-5:], d["cond_rows"][-5:]):
+            fh.write(str(date) + "," + ",".join(repr(float(x)) for x in row) + "\n")
+    rc = G.main(["--date", "2025-11-10", "--n_samples", "40", "--output_dir", str(tmp_path / "out"),
+                 "--checkpoint", str(ckpt), "--conditioning_csv", str(csv), "--seed", "1"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Spot price:" in out and "Valid surfaces:" in out       # parsed by the reference's assistant
+    saved = torch.load(tmp_path / "out" / "2025-11-10" / "iv_surfaces.pt", weights_only=False)
+    for key in ("date", "params", "surfaces", "mean_surface", "median_surface", "p5_surface",
+                "p95_surface", "T_grid", "logm_grid", "spot", "r", "q"):
+        assert key in saved
+    assert saved["params"].shape == (40, 5) and saved["mean_surface"].shape == (8, 21)
+    text = open(tmp_path / "out" / "2025-11-10" / "mean_iv_surface.csv").read().splitlines()
+    assert text[0].startswith(",-20.0%,-18.0%") and text[1].startswith("1M,") and text[-1].startswith("24M,")
+
+
+def test_regime_functions_match_reference_outputs(mods, golden_dir):
+    R = mods["generate_regime_surfaces"]
+    g = np.load(f"{golden_dir}/golden_flags.npz")
+    spot, r, q = float(g["spot"]), float(g["r"]), float(g["q"])
+    for i in (0, 5, 64, 70, 84, 90, 103):
+        res = R.check_all_arbitrage(g["iv"][i], g["tau"], g["logm"], spot, r, q)
+        ref = g["result"][i]
+        if ref[0] < 0:
+            assert res is None
+            assert R.check_static_arbitrage(g["iv"][i], g["tau"], g["logm"], spot, r, q) is None
+            continue
+        assert res == {"static_violations": int(ref[0]), "calendar_violations": int(ref[1]),
+                       "total_violations": int(ref[2]), "is_arbitrage_free": bool(ref[3])}
+        sv = R.check_static_arbitrage(g["iv"][i], g["tau"], g["logm"], spot, r, q)
+        cv = R.check_calendar_arbitrage(g["iv"][i], g["tau"], g["logm"], spot, r, q)
+        assert len(sv) == ref[0] and len(cv) == ref[1]
+        assert all(0 <= m < 8 and 0 <= k < 20 for m, k in sv)
+        assert all(0 <= m < 7 and 0 <= k < 21 for m, k in cv)
+    p = np.array([1.2, 0.04, 0.5, -0.6, 0.05])
+    iv, ok = R.generate_iv_surface(p, g["tau"], g["logm"], spot, r, q)
+    ratio = oracle.price_ratio_grid(p, g["logm"], g["tau"], r, q)
+    ref_iv = oracle.implied_vol_grid(ratio, g["logm"], g["tau"], spot, r, q, "B")[0]
+    assert ok == (not np.isnan(ref_iv).any())
+    m = ~np.isnan(iv) & ~np.isnan(ref_iv)
+    assert np.median(np.abs(iv[m] - ref_iv[m])) <= 1e-9
+    stats = R.regime_statistics(np.tile(p, (6, 1)) * (1 + 0.01 * np.arange(6))[:, None],
+                                g["tau"], g["logm"], spot, r, q)
+    assert stats is None or stats["mean_surface"].shape == (8, 21)
