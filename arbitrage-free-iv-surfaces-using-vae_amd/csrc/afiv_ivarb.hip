@@ -11,24 +11,53 @@
 //                 lands on the same root.
 //   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
 #include "afiv_internal.h"
+#include "erfcx_table.inc"
 
 namespace {
 
-__device__ __forceinline__ double ndtr_dev(double a)
+// Normal CDF through one scaled complementary error function: N(a) = erfc(-a/sqrt 2)/2 with
+// erfc(u) = exp(-u^2) erfcx(u), erfcx from a 64-segment degree-8 table in y = 1/(1+u) (see
+// tools/gen_erfcx_table.py; 1.5 ulp).  One code path for every lane -- the C library's erf/erfc
+// pick one of five ranges per argument, which a wave executes back to back when its lanes
+// disagree.  The table lives in LDS (ERFCX_LDS doubles, filled by load_erfcx_table).
+__constant__ double c_erfcx[AFIV_ERFCX_NSEG * AFIV_ERFCX_NCOEF] = {AFIV_ERFCX_TABLE};
+constexpr int ERFCX_ROW = 10;                       // 9 coefficients padded to 80 B rows
+constexpr int ERFCX_LDS = AFIV_ERFCX_NSEG * ERFCX_ROW;
+static_assert(AFIV_ERFCX_NCOEF == 9 && AFIV_ERFCX_NSEG == 64, "erfcx table shape");
+
+__device__ __forceinline__ void load_erfcx_table(double *lds_tab)
 {
-    // scipy.special.ndtr branch structure (Cephes ndtr.c)
-    if (isnan(a)) return a;
+    for (int i = threadIdx.x; i < ERFCX_LDS; i += blockDim.x) {
+        const int seg = i / ERFCX_ROW, j = i - seg * ERFCX_ROW;
+        lds_tab[i] = j < AFIV_ERFCX_NCOEF ? c_erfcx[seg * AFIV_ERFCX_NCOEF + j] : 0.0;
+    }
+}
+
+__device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ tab)
+{
     const double sqrth = 7.07106781186547524401E-1;
     const double x = a * sqrth;
-    const double z = fabs(x);
-    double y;
-    if (z < sqrth) {
-        y = 0.5 + 0.5 * erf(x);
-    } else {
-        y = 0.5 * erfc(z);
-        if (x > 0) y = 1.0 - y;
-    }
-    return y;
+    const double u = fabs(x);
+    const double t = 64.0 / (1.0 + u);
+    const int seg = (int)fmin(t, 63.0);             // NaN selects a valid row; f stays NaN
+    const double f = (t - (double)seg) - 0.5;
+    const double *c = tab + seg * ERFCX_ROW;
+    double p = c[8];
+    p = fma(p, f, c[7]);
+    p = fma(p, f, c[6]);
+    p = fma(p, f, c[5]);
+    p = fma(p, f, c[4]);
+    p = fma(p, f, c[3]);
+    p = fma(p, f, c[2]);
+    p = fma(p, f, c[1]);
+    p = fma(p, f, c[0]);
+    const double uc = fmin(u, 40.0);                // exp(-u^2) is zero long before
+    const double s = uc * uc;
+    const double lo = fma(uc, uc, -s);              // exact low part of the square
+    double e = exp(-s);
+    e = fma(-e, lo, e);
+    const double h = 0.5 * e * p;                   // erfc(|x|)/2
+    return x > 0 ? 1.0 - h : h;
 }
 
 // Per-point constants of the Black-Scholes objective.
@@ -44,30 +73,31 @@ struct BsPoint {
 };
 
 template <int VARIANT>
-__device__ __forceinline__ double bs_price(const BsPoint &c, double iv)
+__device__ __forceinline__ double bs_price(const BsPoint &c, double iv, const double *__restrict__ tab)
 {
     if (VARIANT == AFIV_VARIANT_A) {
         const double d1 = (c.lnFK + 0.5 * (iv * iv) * c.tau) / (iv * c.sqrt_tau);
         const double d2 = d1 - iv * c.sqrt_tau;
-        return c.disc * (c.F * ndtr_dev(d1) - c.K * ndtr_dev(d2));
+        return c.disc * (c.F * ndtr_dev(d1, tab) - c.K * ndtr_dev(d2, tab));
     } else {
         if (iv <= 0 || c.tau <= 0) return 1e10;
         const double d1 = (c.logm + (c.rq + 0.5 * (iv * iv)) * c.tau) / (iv * c.sqrt_tau);
         const double d2 = d1 - iv * c.sqrt_tau;
-        return c.sdq * ndtr_dev(d1) - c.kdr * ndtr_dev(d2);
+        return c.sdq * ndtr_dev(d1, tab) - c.kdr * ndtr_dev(d2, tab);
     }
 }
 
 // scipy/optimize/Zeros/brentq.c with the Python wrapper's NaN check; NaN on any failure.
 template <int VARIANT>
-__device__ double brentq_dev(const BsPoint &c, double xa, double xb, double xtol, double rtol, int maxiter)
+__device__ double brentq_dev(const BsPoint &c, const double *__restrict__ tab, double xa, double xb,
+                             double xtol, double rtol, int maxiter)
 {
     double xpre = xa, xcur = xb, xblk = 0.0, fpre, fcur, fblk = 0.0, spre = 0.0, scur = 0.0;
     double sbis, delta, stry, dpre, dblk;
     const double nan = __builtin_nan("");
-    fpre = bs_price<VARIANT>(c, xpre) - c.target;
+    fpre = bs_price<VARIANT>(c, xpre, tab) - c.target;
     if (isnan(fpre)) return nan;
-    fcur = bs_price<VARIANT>(c, xcur) - c.target;
+    fcur = bs_price<VARIANT>(c, xcur, tab) - c.target;
     if (isnan(fcur)) return nan;
     if (fpre == 0) return xpre;
     if (fcur == 0) return xcur;
@@ -100,7 +130,7 @@ __device__ double brentq_dev(const BsPoint &c, double xa, double xb, double xtol
         xpre = xcur; fpre = fcur;
         if (fabs(scur) > delta) xcur += scur;
         else xcur += (sbis > 0 ? delta : -delta);
-        fcur = bs_price<VARIANT>(c, xcur) - c.target;
+        fcur = bs_price<VARIANT>(c, xcur, tab) - c.target;
         if (isnan(fcur)) return nan;
     }
     return nan;   // not converged: the reference's brentq raises -> NaN
@@ -128,6 +158,9 @@ __global__ __launch_bounds__(256) void implied_vol_kernel(GridView g, const doub
                                                           int64_t total, double spot,
                                                           double *__restrict__ iv_out)
 {
+    __shared__ double tab[ERFCX_LDS];
+    load_erfcx_table(tab);
+    __syncthreads();
     const int per = g.nT * g.nK;
     const double nan = __builtin_nan("");
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -142,11 +175,11 @@ __global__ __launch_bounds__(256) void implied_vol_kernel(GridView g, const doub
         if (VARIANT == AFIV_VARIANT_A) {
             const double intrinsic = fmax(c.F - c.K, 0.0) * c.disc;
             if (hp < intrinsic * 0.99) iv = nan;
-            else iv = brentq_dev<VARIANT>(c, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+            else iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
         } else {
             if (hp < 1e-10 || isnan(pr)) iv = nan;
             else {
-                iv = brentq_dev<VARIANT>(c, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+                iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
                 if (isnan(iv) || iv <= 0 || iv > 3.0) iv = nan;
             }
         }
@@ -174,6 +207,8 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
     __shared__ double price[MAX_PTS];
     __shared__ int skip_t[AFIV_MAX_MATURITIES];
     __shared__ int counters[5];      // nan, invalid, static, calendar, butterfly
+    __shared__ double tab[ERFCX_LDS];
+    load_erfcx_table(tab);
     const int nT = g.nT, nK = g.nK, per = nT * nK;
     const int tid = threadIdx.x;
     for (int64_t s = blockIdx.x; s < N; s += gridDim.x) {
@@ -189,7 +224,7 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
             if (isnan(x)) { n_nan++; n_bad++; }
             else if (x <= 0) n_bad++;
             BsPoint c = make_point(g, t, k, spot);
-            price[i] = bs_price<BSFORM>(c, x);
+            price[i] = bs_price<BSFORM>(c, x, tab);
             if (pr) {
                 const double y = pr[i];
                 if (isnan(y) || y < 0) skip_t[t] = 1;      // benign race: all writers store 1
