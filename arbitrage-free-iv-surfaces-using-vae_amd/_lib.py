@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libafiv.so")
+# AFIV_LIB_PATH selects another build of the same library (kernel-shape experiments)
+LIB_PATH = os.environ.get("AFIV_LIB_PATH") or os.path.join(_HERE, "libafiv.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -49,6 +50,7 @@ SIGNATURES = {
     "afiv_arbitrage_penalty": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "afiv_stage1_objective": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_double,
                                       c_void_p, c_void_p]),
+    "afiv_debug_math": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -187,6 +187,25 @@ class Grid:
         return out
 
 
+MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5}
+
+
+def debug_math(op: str, x: torch.Tensor, y: torch.Tensor | None = None):
+    """Element-wise evaluation of one of the kernels' own elementary functions (unit tests)."""
+    x = x.contiguous()
+    if x.dtype != torch.float64 or not x.is_cuda:
+        raise TypeError("x must be a CUDA float64 tensor")
+    out0 = torch.empty_like(x)
+    out1 = torch.empty_like(x) if op == "sincos" else None
+    if y is not None:
+        y = y.contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().afiv_debug_math(MATH_OPS[op], _ptr(x), _ptr(y), x.numel(), _ptr(out0), _ptr(out1),
+                                        _stream())
+    _lib.check(rc, "afiv_debug_math")
+    return (out0, out1) if op == "sincos" else out0
+
+
 _DEC_LINEAR = (0, 4, 8, 12)
 _DEC_BN = (1, 5, 9)
 

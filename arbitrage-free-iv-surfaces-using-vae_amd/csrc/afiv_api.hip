@@ -286,4 +286,16 @@ int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const d
                               as_stream(stream));
 }
 
+int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
+                    void *stream)
+{
+    if (n < 0) return AFIV_E_SHAPE;
+    if (op < 0 || op > AFIV_MATH_NDTR) return AFIV_E_ARG;
+    if (n == 0) return AFIV_OK;
+    if (!x || !out0) return AFIV_E_NULL;
+    if (op == AFIV_MATH_ATAN2 && !y) return AFIV_E_NULL;
+    if (op == AFIV_MATH_NDTR) return afiv_launch_debug_ndtr(x, n, out0, as_stream(stream));
+    return afiv_launch_debug_math(op, x, y, n, out0, out1, as_stream(stream));
+}
+
 }  // extern "C"

@@ -64,3 +64,6 @@ int afiv_launch_penalty(const GridView &g, const double *ratio, int64_t B, doubl
 int afiv_launch_stage1(const GridView &g, const double *model_ratio, const double *params,
                        int64_t C, const double *market_ratio, int64_t D, double drift_weight,
                        double *loss_out, hipStream_t s);
+int afiv_launch_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
+                           hipStream_t s);
+int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t s);

@@ -361,7 +361,26 @@ __global__ __launch_bounds__(256) void stage1_kernel(GridView g, const double *_
     }
 }
 
+// Unit-test hook: the normal CDF used by the kernels above, element-wise.
+__global__ void debug_ndtr_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ out)
+{
+    __shared__ double tab[ERFCX_LDS];
+    load_erfcx_table(tab);
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = ndtr_dev(x[i], tab);
+}
+
 }  // namespace
+
+int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(debug_ndtr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
                             double *iv_out, hipStream_t s)

@@ -1,0 +1,152 @@
+// FP64 elementary functions written for these kernels (gfx950, wave64).
+//
+// Why not the device math library: its double-precision exp / log / sincos / atan2 cost 40 / 95 /
+// 155 / 100 vector instructions each and carry a Payne-Hanek reduction and special-value handling
+// that these kernels never need but whose registers are allocated all the same.  The functions
+// below have ONE code path (no data-dependent branches, so a wave never executes two variants back
+// to back), assume finite arguments of moderate size, and cost 20-50 instructions.
+//
+// Accuracy (tests/test_gpu_math.py checks each against 50-digit references):
+//   exp_f64      relative 2 ulp for x in [-745, 709]; 0 below, +inf above
+//   sincos_f64   ABSOLUTE error <= 3e-16 for |x| < 1e9 (3-term Cody-Waite; sin and cos only ever
+//                multiply an amplitude here, so absolute error is what matters)
+//   log1p_f64    relative 2 ulp for f > -1 (relative accuracy near f = 0 is the point: the
+//                characteristic function divides this logarithm by sigma_v^2)
+//   atan2_f64    relative 2 ulp, all quadrants, finite arguments not both zero
+//   rcp_f64      relative 1 ulp for normal x (v_rcp_f64 + two Newton steps)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "afiv_math_coeffs.inc"
+
+namespace afivm {
+
+__device__ __forceinline__ double rcp_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ double exp_f64(double x)
+{
+    const double xc = fmin(fmax(x, -1000.0), 1000.0);          // keeps k inside int range; NaN -> finite garbage is avoided below
+    const double k = __builtin_rint(xc * AFIV_LOG2E);
+    double r = __builtin_fma(k, -AFIV_LN2_HI, xc);
+    r = __builtin_fma(k, -AFIV_LN2_LO, r);
+    double p = AFIV_EXP_C13;
+    p = __builtin_fma(p, r, AFIV_EXP_C12);
+    p = __builtin_fma(p, r, AFIV_EXP_C11);
+    p = __builtin_fma(p, r, AFIV_EXP_C10);
+    p = __builtin_fma(p, r, AFIV_EXP_C9);
+    p = __builtin_fma(p, r, AFIV_EXP_C8);
+    p = __builtin_fma(p, r, AFIV_EXP_C7);
+    p = __builtin_fma(p, r, AFIV_EXP_C6);
+    p = __builtin_fma(p, r, AFIV_EXP_C5);
+    p = __builtin_fma(p, r, AFIV_EXP_C4);
+    p = __builtin_fma(p, r, AFIV_EXP_C3);
+    p = __builtin_fma(p, r, AFIV_EXP_C2);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double y = __builtin_ldexp(p, (int)k);                // v_ldexp_f64: exact scaling, graceful under/overflow
+    return x != x ? x : y;                                      // NaN in, NaN out
+}
+
+// sin and cos of the same argument.
+__device__ __forceinline__ void sincos_f64(double x, double *s_out, double *c_out)
+{
+    const double k = __builtin_rint(x * AFIV_TWO_OVER_PI);
+    double r = __builtin_fma(k, -AFIV_PIO2_1, x);
+    r = __builtin_fma(k, -AFIV_PIO2_2, r);
+    r = __builtin_fma(k, -AFIV_PIO2_3, r);
+    const int q = (int)k;
+    const double z = r * r;
+    double ps = AFIV_SIN_C5;
+    ps = __builtin_fma(ps, z, AFIV_SIN_C4);
+    ps = __builtin_fma(ps, z, AFIV_SIN_C3);
+    ps = __builtin_fma(ps, z, AFIV_SIN_C2);
+    ps = __builtin_fma(ps, z, AFIV_SIN_C1);
+    ps = __builtin_fma(ps, z, AFIV_SIN_C0);
+    const double sn = __builtin_fma(r * z, ps, r);
+    double pc = AFIV_COS_C5;
+    pc = __builtin_fma(pc, z, AFIV_COS_C4);
+    pc = __builtin_fma(pc, z, AFIV_COS_C3);
+    pc = __builtin_fma(pc, z, AFIV_COS_C2);
+    pc = __builtin_fma(pc, z, AFIV_COS_C1);
+    pc = __builtin_fma(pc, z, AFIV_COS_C0);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    // quadrant: x = r + q pi/2
+    const bool swap = q & 1;
+    double s = swap ? cs : sn;
+    double c = swap ? sn : cs;
+    s = (q & 2) ? -s : s;
+    c = ((q + 1) & 2) ? -c : c;
+    *s_out = s;
+    *c_out = c;
+}
+
+// log(1 + f).  For |f| small the argument is used as is (exact); otherwise 1 + f is split into
+// m 2^e with m in [sqrt(1/2), sqrt(2)) and the rounding of 1 + f is corrected to first order.
+__device__ __forceinline__ double log1p_f64(double f)
+{
+    const double u = 1.0 + f;
+    // c = f - (u - 1): what the rounding of 1 + f lost (exact when |f| <= 1)
+    const double c = (f - (u - 1.0));
+    int e = __builtin_amdgcn_frexp_exp(u);                      // u = mant 2^e, mant in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(u);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    // g = m - 1 (exact), plus the correction term scaled like m
+    const double scale = __builtin_ldexp(1.0, -e);
+    const bool small = e == 0;
+    // when e == 0, m == u and (m - 1) + c == f up to the rounding already inside f itself
+    const double g = small ? f : __builtin_fma(c, scale, m - 1.0);
+    const double s = g * rcp_f64(2.0 + g);
+    const double z = s * s;
+    double p = AFIV_LOG_C6;
+    p = __builtin_fma(p, z, AFIV_LOG_C5);
+    p = __builtin_fma(p, z, AFIV_LOG_C4);
+    p = __builtin_fma(p, z, AFIV_LOG_C3);
+    p = __builtin_fma(p, z, AFIV_LOG_C2);
+    p = __builtin_fma(p, z, AFIV_LOG_C1);
+    p = __builtin_fma(p, z, AFIV_LOG_C0);
+    // log(1+g) = 2 atanh(s) = 2 s + s z P(z) = g - s (g - z P(z))
+    const double lg = g - s * (g - z * p);
+    const double ed = (double)e;
+    return __builtin_fma(ed, AFIV_LN2_HI, __builtin_fma(ed, AFIV_LN2_LO, lg));
+}
+
+// atan2(y, x) for finite arguments, not both zero.
+__device__ __forceinline__ double atan2_f64(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    // t = mn/mx in [0,1]; above tan(pi/8) use atan t = pi/4 + atan((t-1)/(t+1)) with one division
+    const bool hi = mn > AFIV_TAN_PIO8 * mx;
+    const double num = hi ? mn - mx : mn;
+    const double den = hi ? mn + mx : mx;
+    const double t = num * rcp_f64(den);
+    const double z = t * t;
+    double p = AFIV_ATAN_C11;
+    p = __builtin_fma(p, z, AFIV_ATAN_C10);
+    p = __builtin_fma(p, z, AFIV_ATAN_C9);
+    p = __builtin_fma(p, z, AFIV_ATAN_C8);
+    p = __builtin_fma(p, z, AFIV_ATAN_C7);
+    p = __builtin_fma(p, z, AFIV_ATAN_C6);
+    p = __builtin_fma(p, z, AFIV_ATAN_C5);
+    p = __builtin_fma(p, z, AFIV_ATAN_C4);
+    p = __builtin_fma(p, z, AFIV_ATAN_C3);
+    p = __builtin_fma(p, z, AFIV_ATAN_C2);
+    p = __builtin_fma(p, z, AFIV_ATAN_C1);
+    p = __builtin_fma(p, z, AFIV_ATAN_C0);
+    double a = __builtin_fma(t * z, p, t);                      // atan of the reduced argument
+    a = hi ? a + AFIV_PIO4 : a;                                 // angle of (mx, mn) in [0, pi/4]
+    a = ay > ax ? 2.0 * AFIV_PIO4 - a : a;                      // first octant pair
+    a = x < 0.0 ? AFIV_PI - a : a;
+    return __builtin_copysign(a, y);
+}
+
+}  // namespace afivm

@@ -14,29 +14,43 @@
 // a [rows x 576] x [576 x strikes] FP64 contraction against strike tables that depend only on the
 // grid (phase 2, v_mfma_f64_16x16x4_f64).
 //
-// Work decomposition: one workgroup = 2 surfaces = 576 threads = 9 full wave64s; thread =
-// (surface, j, node).  Maturity-independent quantities (d, p, 1/(1-p), ...) stay in registers
-// while the thread walks the maturities in tiles of 8, so a tile fills the 16 rows of one MFMA
-// row block (2 surfaces x 8 maturities).  Phase 1 writes the 16 x 576 operand block to LDS;
-// phase 2 splits the 576-long contraction over the 9 waves (64 each), each wave issuing
-// 16 x (nKpad/16) MFMAs with B fragments streamed from the L2-resident table; partial tiles are
-// reduced through LDS in a fixed order (bitwise reproducible).
+// Work decomposition: one workgroup = 5 surfaces x 144 Laguerre nodes = 720 of 768 threads =
+// 12 waves, i.e. 3 per SIMD (balanced); a thread owns one node of one surface and evaluates both
+// integrals j = 1, 2.  Maturity-independent quantities (d, t1-d, p, 1/(1-p)) stay in registers.
+// The workgroup advances in steps of 3 maturities: 5 surfaces x 3 maturities fill 15 of the 16
+// rows of one MFMA row block.  Phase 1 of step G writes its 16 x 576 operand block into one half
+// of a double-buffered LDS area while phase 2 of step G-1 reads the other half: each wave owns
+// one (column tile, K range) of the contraction and issues its MFMA chain after a different one
+// of the step's six characteristic-function evaluations (waves w, w+4, w+8 share a SIMD), so
+// the matrix pipe works in the shadow of the other waves' vector work.  B fragments stream
+// from the L2-resident table; partial tiles are reduced through LDS in a fixed order (bitwise
+// reproducible results).
 #include "afiv_internal.h"
+#include "afiv_math.h"
 #include "laguerre144.inc"
 
 namespace {
 
 constexpr int NQ = AFIV_NQ_NODES;          // 144
 constexpr int KDIM = AFIV_KDIM;            // 576
-constexpr int SURF_PER_BLOCK = 2;
-constexpr int THREADS = SURF_PER_BLOCK * 2 * NQ;   // 576
-constexpr int WAVES = THREADS / 64;        // 9
-constexpr int MT = 8;                      // maturities per tile
-constexpr int ROWS = SURF_PER_BLOCK * MT;  // 16 = MFMA M
+// Workgroup shape.  5 surfaces x 144 nodes = 720 of 768 lanes (12 waves, 3 per SIMD, <= 168
+// VGPRs without spilling); 5 surfaces x 3 maturities fill 15 of the 16 MFMA rows.  Measured
+// alternatives on MI355X (20 x 50 lattice, 131 072 surfaces): 3 x 512 / 5 maturities 14.1 ms,
+// 5 x 768 / 3 maturities 13.3 ms, 7 x 1024 / 2 maturities 24.3 ms (128-VGPR cap -> scratch spills).
+#ifndef AFIV_SPB
+#define AFIV_SPB 5
+#define AFIV_THREADS 768
+#define AFIV_MT 3
+#endif
+constexpr int SPB = AFIV_SPB;              // surfaces per workgroup
+constexpr int THREADS = AFIV_THREADS;
+constexpr int WAVES = THREADS / 64;
+constexpr int MT = AFIV_MT;                // maturities per step
+constexpr int NEVAL = 2 * MT;              // characteristic-function evaluations per thread and step
+constexpr int ROWS = 16;                   // MFMA M; SPB*MT rows carry data
 constexpr int XSTRIDE = KDIM + 2;          // doubles; 1156 dwords = 4 mod 64 -> conflict-free A reads
-constexpr int KSLICE = KDIM / WAVES;       // 64 contraction indices per wave
-constexpr int AFIV_MAX_NKPAD = 64;
-static_assert(KDIM % WAVES == 0 && KSLICE % 4 == 0, "split-K layout");
+constexpr int XBUF = ROWS * XSTRIDE;       // doubles per operand buffer
+static_assert(SPB * MT <= ROWS && SPB * NQ <= THREADS, "row / lane layout");
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -45,10 +59,10 @@ __constant__ double c_lag_wp[NQ] = {AFIV_LAG_WP_LIST};   // W_n / (pi x_n)
 
 struct Cx { double r, i; };
 __device__ __forceinline__ Cx cmul(Cx a, Cx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
-__device__ __forceinline__ Cx cdiv(Cx a, Cx b)
+__device__ __forceinline__ Cx crcp(Cx b)
 {
-    const double inv = 1.0 / (b.r * b.r + b.i * b.i);
-    return {(a.r * b.r + a.i * b.i) * inv, (a.i * b.r - a.r * b.i) * inv};
+    const double inv = afivm::rcp_f64(b.r * b.r + b.i * b.i);
+    return {b.r * inv, -b.i * inv};
 }
 __device__ __forceinline__ Cx csqrt_principal(Cx z)
 {
@@ -65,167 +79,235 @@ __device__ __forceinline__ Cx csqrt_principal(Cx z)
     return d;
 }
 
-template <int NCT>
+// Maturity-independent part of A_j(phi) for one integral.
+struct JState { Cx d, a, p, inv1mp; };
+
+struct Model { double sigma2, c1, c2; bool main_branch; };
+
+// QuantLib's Fj_Helper forms d = sqrt(t1^2 - sigma^2 phi u), u = (-phi, +-1), and then the
+// differences t1 - d and t1 + d.  One of the two cancels (d -> +-t1 as sigma -> 0) and the formula
+// divides by sigma^2 afterwards, which is where a double-precision evaluation picks up an
+// absolute noise of eps/sigma^2.  Since (t1 - d)(t1 + d) = sigma^2 phi u exactly, the cancelling
+// one is obtained here from the other by division -- same value, no cancellation.
+template <int J>   // 0 -> P1, 1 -> P2
+__device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rho, const Model &m, double phi)
+{
+    const double sj = J == 0 ? 1.0 : -1.0;
+    const double rsig = rho * sigma;
+    const Cx t1 = {kappa - (J == 0 ? rsig : 0.0), -(rsig * phi)};
+    const Cx u = {-phi, sj};
+    const Cx zz = {t1.r * t1.r - t1.i * t1.i + m.sigma2 * phi * phi,
+                   2.0 * t1.r * t1.i - m.sigma2 * phi * sj};
+    JState s;
+    s.d = csqrt_principal(zz);
+    if (m.main_branch) {
+        const Cx su = {m.sigma2 * phi * u.r, m.sigma2 * phi * u.i};       // sigma^2 phi u
+        Cx sum;
+        if (t1.r >= 0.0) {
+            sum = {t1.r + s.d.r, t1.i + s.d.i};
+            s.a = cmul(su, crcp(sum));
+        } else {
+            s.a = {t1.r - s.d.r, t1.i - s.d.i};
+            sum = cmul(su, crcp(s.a));
+        }
+        s.p = cmul(s.a, crcp(sum));
+        s.inv1mp = crcp(Cx{1.0 - s.p.r, -s.p.i});
+    } else {
+        // vol-of-vol <= 1e-5 series, as the reference engine switches: td = phi/(2 t1) u ;
+        // p = td sigma^2/(t1+d)
+        const Cx h = crcp(Cx{2.0 * t1.r, 2.0 * t1.i});
+        s.a = cmul(Cx{phi * h.r, phi * h.i}, u);
+        s.p = cmul(Cx{s.a.r * m.sigma2, s.a.i * m.sigma2}, crcp(Cx{t1.r + s.d.r, t1.i + s.d.i}));
+        s.inv1mp = {0.0, 0.0};
+    }
+    return s;
+}
+
+// One characteristic-function evaluation: returns (E sin alpha, E cos alpha) with the discount
+// factor of its integral folded in.
+__device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, double phi, double wp,
+                                           double T, double ddt, double disc)
+{
+    const double er = afivm::exp_f64(-s.d.r * T);
+    double sn, cs;
+    afivm::sincos_f64(s.d.i * T, &sn, &cs);
+    const Cx ex = {er * cs, -er * sn};               // exp(-d T)
+    const Cx omex = {1.0 - ex.r, -ex.i};             // 1 - ex
+    const Cx pe = cmul(s.p, ex);
+    const Cx num = {1.0 - pe.r, -pe.i};              // 1 - p ex
+    const Cx f1 = cmul(cmul(s.a, omex), crcp(num));
+    Cx A;
+    if (m.main_branch) {
+        // g = log((1 - p ex)/(1 - p)) = log(1 + w1) with w1 = p (1 - ex)/(1 - p) formed directly,
+        // so that the logarithm keeps its relative accuracy when w1 ~ sigma^2
+        const Cx w1 = cmul(cmul(s.p, omex), s.inv1mp);
+        const double glr = 0.5 * afivm::log1p_f64(__builtin_fma(w1.r, w1.r, __builtin_fma(w1.i, w1.i, 2.0 * w1.r)));
+        const double gli = afivm::atan2_f64(w1.i, 1.0 + w1.r);
+        A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
+        A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
+    } else {
+        const Cx gl = cmul(s.p, omex);               // g = p (1 - ex)
+        A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * gl.r / m.sigma2);
+        A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gl.i / m.sigma2);
+    }
+    const double alpha = A.i + phi * ddt;
+    const double E = wp * afivm::exp_f64(A.r) * disc;
+    double sa, ca;
+    afivm::sincos_f64(alpha, &sa, &ca);
+    return make_double2(E * sa, E * ca);
+}
+
+// NCTP = column tiles rounded up to a power of two (1, 2, 4); the 16 waves split into NCTP column
+// tiles x (16/NCTP) ranges of the 576-long contraction.
+template <int NCTP>
 __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double *__restrict__ params,
                                                         int64_t N, double *__restrict__ ratio_out)
 {
-    __shared__ double lds[ROWS * XSTRIDE];   // operand block, reused for the partial tiles
+    constexpr int KS = WAVES / NCTP;          // K ranges
+    constexpr int KLEN = KDIM / KS;           // contraction indices per wave
+    constexpr int NKP = 16 * NCTP;            // padded strike count used for the partial tiles
+    static_assert(KLEN % 4 == 0, "K range must be a multiple of the MFMA depth");
+    static_assert(KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
+
+    __shared__ double lds[2 * XBUF];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int gsurf = tid / (2 * NQ);        // 0/1: which of the block's two surfaces
-    const int rem = tid - gsurf * 2 * NQ;
-    const int jj = rem / NQ;                 // 0 -> P1, 1 -> P2
-    const int n = rem - jj * NQ;
+    const int sl = tid / NQ;                  // < SPB: real surfaces; == SPB: spare lanes of the last wave
+    const int n = tid - sl * NQ;
     const double phi = c_lag_x[n];
     const double wp = c_lag_wp[n];
-    const double sj = jj == 0 ? 1.0 : -1.0;
-    const int ntiles = (g.nT + MT - 1) / MT;
-    const int nKpad = g.nKpad;
+    const int ct = wave % NCTP, kq = wave / NCTP;
+    // waves w, w+4, ... share a SIMD: they issue their MFMA chain after different evaluations
+    const int my_eval = (wave >> 2) * (NEVAL / (WAVES / 4));
+    const int nT = g.nT, nK = g.nK, nKpad = g.nKpad;
+    const bool ct_live = 16 * ct < nKpad;
+    const int ntiles = (nT + MT - 1) / MT;
+    const int64_t nchunks = (N + SPB - 1) / SPB;
+    const int64_t my_chunks = blockIdx.x < nchunks ? (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t total = my_chunks * ntiles;
 
-    for (int64_t pair = blockIdx.x; pair * SURF_PER_BLOCK < N; pair += gridDim.x) {
-        const int64_t s0 = pair * SURF_PER_BLOCK;
-        int64_t s = s0 + gsurf;
-        if (s >= N) s = N - 1;               // odd tail: duplicate work, never stored
-        const double kappa = params[5 * s + 0], theta = params[5 * s + 1], sigma = params[5 * s + 2],
-                     rho = params[5 * s + 3], v0 = params[5 * s + 4];
+    Model m = {};
+    JState st0 = {}, st1 = {};
+    int64_t prev_chunk = 0;
+    int prev_tile = 0;
 
-        // ---- maturity-independent part of A_j(phi) ------------------------------------------
-        const double sigma2 = sigma * sigma;
-        const double rsig = rho * sigma;
-        const Cx t1 = {kappa - (jj == 0 ? rsig : 0.0), -(rsig * phi)};
-        const Cx u = {-phi, sj};
-        const Cx zz = {t1.r * t1.r - t1.i * t1.i + sigma2 * phi * phi,
-                       2.0 * t1.r * t1.i - sigma2 * phi * sj};
-        const Cx d = csqrt_principal(zz);
-        const bool main_branch = sigma > 1e-5;
-        const double kt = kappa * theta;
-        Cx a, p, inv1mp;
-        double c1, c2;
-        if (main_branch) {
-            a = {t1.r - d.r, t1.i - d.i};                       // t1 - d
-            p = cdiv(a, Cx{t1.r + d.r, t1.i + d.i});
-            inv1mp = cdiv(Cx{1.0, 0.0}, Cx{1.0 - p.r, -p.i});
-            c1 = v0 / sigma2;
-            c2 = kt / sigma2;
-        } else {
-            // small vol-of-vol series: td = phi/(2 t1) * u ; p = td sigma^2/(t1+d)
-            const Cx h = cdiv(Cx{phi, 0.0}, Cx{2.0 * t1.r, 2.0 * t1.i});
-            a = cmul(h, u);                                     // td
-            const Cx q1 = cdiv(Cx{a.r * sigma2, a.i * sigma2}, Cx{t1.r + d.r, t1.i + d.i});
-            p = q1;
-            inv1mp = {0.0, 0.0};
-            c1 = v0;
-            c2 = kt;
+    for (int64_t G = 0; G <= total; ++G) {
+        const bool have_cur = G < total, have_prev = G > 0;
+        const int64_t chunk = blockIdx.x + (G / ntiles) * (int64_t)gridDim.x;
+        const int tile = (int)(G % ntiles);
+        double *xw = lds + (G & 1) * XBUF;                  // written by this step's phase 1
+        double *xr = lds + ((G + 1) & 1) * XBUF;            // operand block of the previous step
+
+        if (have_cur && tile == 0) {
+            int64_t s = chunk * SPB + sl;
+            if (s >= N) s = N - 1;                           // spare lanes / ragged tail: never stored
+            const double kappa = params[5 * s + 0], theta = params[5 * s + 1], sigma = params[5 * s + 2],
+                         rho = params[5 * s + 3], v0 = params[5 * s + 4];
+            m.sigma2 = sigma * sigma;
+            m.main_branch = sigma > 1e-5;
+            m.c1 = m.main_branch ? v0 / m.sigma2 : v0;
+            m.c2 = m.main_branch ? (kappa * theta) / m.sigma2 : kappa * theta;
+            st0 = cf_setup<0>(kappa, sigma, rho, m, phi);
+            st1 = cf_setup<1>(kappa, sigma, rho, m, phi);
         }
 
-        for (int tile = 0; tile < ntiles; ++tile) {
-            // ---- phase 1: operand rows for up to MT maturities ------------------------------
-            for (int tl = 0; tl < MT; ++tl) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < NEVAL; ++e) {
+            if (have_cur) {
+                const int tl = e >> 1;
                 const int t = tile * MT + tl;
-                double x0 = 0.0, x1 = 0.0;
-                if (t < g.nT) {
-                    const double T = g.term[t];
-                    const double er = exp(-d.r * T);
-                    double sn, cs;
-                    sincos(d.i * T, &sn, &cs);
-                    const Cx ex = {er * cs, -er * sn};           // exp(-d T)
-                    const Cx pe = cmul(p, ex);
-                    const Cx num = {1.0 - pe.r, -pe.i};          // 1 - p ex
-                    const Cx omex = {1.0 - ex.r, -ex.i};         // 1 - ex
-                    Cx A;
-                    if (main_branch) {
-                        const Cx w = cmul(num, inv1mp);          // (1 - p ex)/(1 - p)
-                        const Cx gl = {0.5 * log(w.r * w.r + w.i * w.i), atan2(w.i, w.r)};
-                        const Cx f1 = cdiv(cmul(a, omex), num);
-                        A.r = c1 * f1.r + c2 * (a.r * T - 2.0 * gl.r);
-                        A.i = c1 * f1.i + c2 * (a.i * T - 2.0 * gl.i);
-                    } else {
-                        const Cx gl = cmul(p, omex);             // g = p (1 - ex)
-                        const Cx f1 = cdiv(cmul(a, omex), num);
-                        A.r = c1 * f1.r + c2 * (a.r * T - 2.0 * gl.r / sigma2);
-                        A.i = c1 * f1.i + c2 * (a.i * T - 2.0 * gl.i / sigma2);
-                    }
-                    const double alpha = A.i + phi * g.dd[t];
-                    const double E = wp * exp(A.r) * (jj == 0 ? g.Dq[t] : g.Dr[t]);
-                    double sa, ca;
-                    sincos(alpha, &sa, &ca);
-                    x0 = E * sa;
-                    x1 = E * ca;
+                double2 x = make_double2(0.0, 0.0);
+                if (t < nT) {
+                    const double T = g.term[t], ddt = g.dd[t];
+                    x = (e & 1) == 0 ? cf_eval(st0, m, phi, wp, T, ddt, g.Dq[t])
+                                     : cf_eval(st1, m, phi, wp, T, ddt, g.Dr[t]);
                 }
-                double2 *dst = reinterpret_cast<double2 *>(&lds[(gsurf * MT + tl) * XSTRIDE + 2 * (jj * NQ + n)]);
-                *dst = make_double2(x0, x1);
+                if (sl < SPB)     // spare lanes of the last wave own no row
+                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * ((e & 1) * NQ + n)]) = x;
             }
-            __syncthreads();
-
-            // ---- phase 2: [16 x 64-slice] x [64-slice x nKpad] per wave on the matrix pipe ---
-            v4d acc[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4d{0.0, 0.0, 0.0, 0.0};
-            {
-                const int arow = lane & 15;
-                const int kq = lane >> 4;
-                const double *xa = &lds[arow * XSTRIDE + wave * KSLICE + kq];
-                const double *tb = g.tab + (size_t)(wave * KSLICE + kq) * nKpad + (lane & 15);
-#pragma unroll 4
-                for (int ks = 0; ks < KSLICE / 4; ++ks) {
-                    const double av = xa[4 * ks];
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const double bv = tb[(size_t)(4 * ks) * nKpad + 16 * ct];
-                        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ct], 0, 0, 0);
-                    }
-                }
+            if (have_prev && e == my_eval && ct_live) {
+                // [16 x KLEN] x [KLEN x 16] on the matrix pipe
+                const double *xa = xr + (lane & 15) * XSTRIDE + kq * KLEN + (lane >> 4);
+                const double *tb = g.tab + (size_t)(kq * KLEN + (lane >> 4)) * nKpad + 16 * ct + (lane & 15);
+#pragma unroll 6
+                for (int ks = 0; ks < KLEN / 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * ks], tb[(size_t)(4 * ks) * nKpad], acc, 0, 0, 0);
             }
-            __syncthreads();                  // every wave is done reading the operand block
-            {
-                // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
-                double *pw = &lds[wave * ROWS * nKpad];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        pw[((lane >> 4) + 4 * i) * nKpad + 16 * ct + (lane & 15)] = acc[ct][i];
-            }
-            __syncthreads();
-            for (int o = tid; o < ROWS * nKpad; o += THREADS) {
-                const int row = o / nKpad;
-                const int col = o - row * nKpad;
-                const int gs = row / MT;
-                const int t = tile * MT + (row - gs * MT);
-                if (t < g.nT && col < g.nK && s0 + gs < N) {
-                    double sum = 0.0;
-#pragma unroll
-                    for (int w = 0; w < WAVES; ++w) sum += lds[(w * ROWS + row) * nKpad + col];
-                    const double Dq = g.Dq[t], Dr = g.Dr[t], K = g.Kmult[col];
-                    double call = (0.5 * Dq - 0.5 * (K * Dr)) + sum;
-                    if (!(g.term[t] > 0.0)) call = 0.0;          // expired option: NPV 0
-                    ratio_out[((s0 + gs) * g.nT + t) * (int64_t)g.nK + col] = call / g.disc_tau[t];
-                }
-            }
-            __syncthreads();                  // partial tiles consumed before the next phase 1
         }
+        __syncthreads();          // operand block G complete; every MFMA chain of step G-1 done
+        if (have_prev && ct_live) {
+            // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+            double *pw = xr + (kq * ROWS) * NKP + 16 * ct + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[((lane >> 4) + 4 * i) * NKP] = acc[i];
+        }
+        __syncthreads();
+        for (int o = tid; have_prev && o < ROWS * NKP; o += THREADS) {
+            const int row = o / NKP;
+            const int col = o - row * NKP;
+            const int rs = row / MT;
+            const int t = prev_tile * MT + (row - rs * MT);
+            const int64_t s = prev_chunk * SPB + rs;
+            if (rs < SPB && s < N && t < nT && col < nK) {
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < KS; ++q) sum += xr[(q * ROWS + row) * NKP + col];
+                const double Dq = g.Dq[t], Dr = g.Dr[t], K = g.Kmult[col];
+                double call = (0.5 * Dq - 0.5 * (K * Dr)) + sum;
+                if (!(g.term[t] > 0.0)) call = 0.0;          // expired option: NPV 0
+                ratio_out[(s * nT + t) * (int64_t)nK + col] = call / g.disc_tau[t];
+            }
+        }
+        __syncthreads();          // partial tiles consumed before step G+1 overwrites this buffer
+        prev_chunk = chunk;
+        prev_tile = tile;
     }
 }
 
-static_assert(WAVES * ROWS * AFIV_MAX_NKPAD <= ROWS * XSTRIDE, "partial tiles must fit in the operand block");
+// Unit-test hook: the elementary functions above, element-wise.
+__global__ void debug_math_kernel(int op, const double *__restrict__ x, const double *__restrict__ y, int64_t n,
+                                  double *__restrict__ out0, double *__restrict__ out1)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0, b = 0.0;
+        switch (op) {
+            case 0: a = afivm::exp_f64(x[i]); break;
+            case 1: afivm::sincos_f64(x[i], &a, &b); break;
+            case 2: a = afivm::log1p_f64(x[i]); break;
+            case 3: a = afivm::atan2_f64(x[i], y[i]); break;
+            case 4: a = afivm::rcp_f64(x[i]); break;
+            default: break;
+        }
+        out0[i] = a;
+        if (out1) out1[i] = b;
+    }
+}
 
 }  // namespace
+
+int afiv_launch_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
+                           hipStream_t s)
+{
+    if (n <= 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)blocks), dim3(256), 0, s, op, x, y, n, out0, out1);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int afiv_launch_price(const GridView &g, const double *params, int64_t N, double *ratio_out, hipStream_t s)
 {
     if (N <= 0) return 0;
     const int nct = g.nKpad / 16;
-    const size_t lds_bytes = 0;   // LDS is static
-    int64_t pairs = (N + SURF_PER_BLOCK - 1) / SURF_PER_BLOCK;
-    int64_t blocks = pairs < 256 * 64 ? pairs : 256 * 64;
+    if (nct < 1 || nct > 4) return -2;
+    const int64_t chunks = (N + SPB - 1) / SPB;
+    // one workgroup per CU is resident (LDS); a few waves of workgroups per CU balance the tail
+    const int64_t blocks = chunks < 256 * 8 ? chunks : 256 * 8;
     dim3 grid((unsigned)blocks), block(THREADS);
-    switch (nct) {
-        case 1: hipLaunchKernelGGL(price_kernel<1>, grid, block, lds_bytes, s, g, params, N, ratio_out); break;
-        case 2: hipLaunchKernelGGL(price_kernel<2>, grid, block, lds_bytes, s, g, params, N, ratio_out); break;
-        case 3: hipLaunchKernelGGL(price_kernel<3>, grid, block, lds_bytes, s, g, params, N, ratio_out); break;
-        case 4: hipLaunchKernelGGL(price_kernel<4>, grid, block, lds_bytes, s, g, params, N, ratio_out); break;
-        default: return -2;
-    }
+    if (nct == 1) hipLaunchKernelGGL(price_kernel<1>, grid, block, 0, s, g, params, N, ratio_out);
+    else if (nct == 2) hipLaunchKernelGGL(price_kernel<2>, grid, block, 0, s, g, params, N, ratio_out);
+    else hipLaunchKernelGGL(price_kernel<4>, grid, block, 0, s, g, params, N, ratio_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

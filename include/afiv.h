@@ -145,6 +145,17 @@ int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const d
                           int64_t C, const double *market_ratio, int64_t D, double drift_weight,
                           double *loss_out, void *stream);
 
+/* ---- diagnostics: the kernels' own FP64 elementary functions, element-wise, so that unit tests
+ * can check them against high-precision references.  No counterpart in the reference (which
+ * calls libm / SciPy).  x, y, out0, out1: device [n]; y only for AFIV_MATH_ATAN2 (atan2(x, y));
+ * out1 only for AFIV_MATH_SINCOS (out0 = sin, out1 = cos; may be NULL). */
+enum {
+    AFIV_MATH_EXP = 0, AFIV_MATH_SINCOS = 1, AFIV_MATH_LOG1P = 2, AFIV_MATH_ATAN2 = 3,
+    AFIV_MATH_RCP = 4, AFIV_MATH_NDTR = 5
+};
+int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

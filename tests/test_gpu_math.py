@@ -1,0 +1,89 @@
+"""The kernels' own FP64 elementary functions against 50-digit references (mpmath)."""
+import mpmath as mp
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+mp.mp.dps = 50
+EPS = np.finfo(np.float64).eps
+
+
+def run(afiv, op, x, y=None):
+    xd = torch.tensor(x, dtype=torch.float64, device="cuda")
+    yd = None if y is None else torch.tensor(y, dtype=torch.float64, device="cuda")
+    out = afiv.debug_math(op, xd, yd)
+    if op == "sincos":
+        return out[0].cpu().numpy(), out[1].cpu().numpy()
+    return out.cpu().numpy()
+
+
+def relerr(got, ref):
+    return np.array([abs(float((mp.mpf(float(g)) - r) / r)) if r != 0 else abs(float(g)) for g, r in zip(got, ref)])
+
+
+def test_exp(afiv):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-700, 700, 3000), rng.uniform(-2, 2, 3000), [0.0, -745.0, 709.0, 1e-300]])
+    got = run(afiv, "exp", x)
+    ref = [mp.exp(mp.mpf(float(v))) for v in x]
+    normal = np.array([float(r) > 1e-300 for r in ref])        # subnormal results: absolute only
+    assert relerr(got[normal], [r for r, k in zip(ref, normal) if k]).max() <= 3 * EPS
+    assert np.all(got[~normal] < 1e-300)
+    edge = run(afiv, "exp", np.array([-1e300, -800.0, 800.0, np.inf, -np.inf, np.nan]))
+    assert edge[0] == 0 and edge[1] == 0 and np.isinf(edge[2]) and np.isinf(edge[3]) and edge[4] == 0
+    assert np.isnan(edge[5])
+
+
+def test_sincos_absolute_accuracy(afiv):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-10, 10, 3000), rng.uniform(-6000, 6000, 3000),
+                        rng.uniform(-1e6, 1e6, 2000), rng.uniform(-1e9, 1e9, 1000),
+                        [0.0, np.pi / 4, np.pi / 2, -np.pi, 1e-300]])
+    s, c = run(afiv, "sincos", x)
+    es = np.array([abs(float(mp.mpf(float(a)) - mp.sin(mp.mpf(float(v))))) for a, v in zip(s, x)])
+    ec = np.array([abs(float(mp.mpf(float(a)) - mp.cos(mp.mpf(float(v))))) for a, v in zip(c, x)])
+    assert es.max() <= 3e-16 and ec.max() <= 3e-16
+
+
+def test_log1p_relative_accuracy(afiv):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-0.9, 5, 3000), 10.0 ** rng.uniform(-20, 6, 2000),
+                        -(10.0 ** rng.uniform(-20, -0.2, 2000)), [0.0, 1e-300, -0.29, 0.41, 1.0, 3.0]])
+    got = run(afiv, "log1p", x)
+    ref = [mp.log1p(mp.mpf(float(v))) for v in x]
+    assert relerr(got, ref).max() <= 3 * EPS
+
+
+def test_atan2_all_quadrants(afiv):
+    rng = np.random.default_rng(3)
+    n = 6000
+    y = rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 3, n)
+    x = rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 3, n)
+    y = np.concatenate([y, [0.0, 1.0, -1.0, 1e-300, 0.4142135623730950, 1.0]])
+    x = np.concatenate([x, [-1.0, 0.0, 0.0, 1.0, 1.0, 1.0]])
+    got = run(afiv, "atan2", y, x)
+    ref = [mp.atan2(mp.mpf(float(a)), mp.mpf(float(b))) for a, b in zip(y, x)]
+    assert relerr(got, ref).max() <= 3 * EPS
+
+
+def test_rcp(afiv):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(4000) * 10.0 ** rng.uniform(-100, 100, 4000)
+    got = run(afiv, "rcp", x)
+    assert np.max(np.abs(got * x - 1.0)) <= 3 * EPS
+
+
+def test_ndtr_against_reference(afiv):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-8, 8, 6000), rng.uniform(-38, -8, 1000), [0.0, -0.0, 40.0, -40.0, np.inf, -np.inf]])
+    got = run(afiv, "ndtr", x)
+    ref = [mp.ncdf(mp.mpf(float(v))) for v in x]
+    refd = np.array([float(r) for r in ref])
+    # absolute: an ulp of 1.0; relative in the lower tail: a few ulp plus the rounding of the
+    # argument's own scaling by 1/sqrt(2), which exp(-x^2/2) amplifies by x^2 (1.2e-13 at x = -33)
+    assert np.max(np.abs(got - refd)) <= 2.5e-16
+    tail = (x < 0) & (refd > 1e-300)
+    rel = relerr(got[tail], [r for r, t in zip(ref, tail) if t])
+    assert np.all(rel <= 4 * EPS * (1 + x[tail] ** 2))
+    assert np.isnan(run(afiv, "ndtr", np.array([np.nan]))[0])
