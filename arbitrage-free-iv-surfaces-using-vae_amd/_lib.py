@@ -41,6 +41,8 @@ SIGNATURES = {
     "afiv_implied_vol": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p]),
     "afiv_arb_check": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p,
                                c_void_p]),
+    "afiv_implied_vol_checked": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p,
+                                         c_void_p]),
     "afiv_surface": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "afiv_decoder_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(DecoderWeights)]),

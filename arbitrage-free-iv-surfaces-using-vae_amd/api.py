@@ -136,6 +136,21 @@ class Grid:
         _lib.check(rc, "afiv_arb_check")
         return (flags, mask) if want_mask else flags
 
+    def implied_vol_checked(self, ratio: torch.Tensor, spot: float, variant="A",
+                            iv_out: torch.Tensor | None = None, flags_out: torch.Tensor | None = None):
+        """Implied vols and flag words in one pass (same results as implied_vol + arb_check with
+        bs_form = variant).  Returns (iv, flags)."""
+        ra = self._lattice(ratio, "ratio")
+        n = ra.shape[0]
+        iv = torch.empty_like(ra) if iv_out is None else self._lattice(iv_out, "iv_out")
+        flags = torch.empty((n, 4), dtype=torch.int32, device=self.device) \
+            if flags_out is None else _need(flags_out, torch.int32, "flags_out", self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().afiv_implied_vol_checked(self._h, _ptr(ra), n, float(spot), VARIANTS[variant],
+                                                     _ptr(iv), _ptr(flags), _stream())
+        _lib.check(rc, "afiv_implied_vol_checked")
+        return iv, flags
+
     def surface(self, params: torch.Tensor, spot: float, variant="A", keep_ratio: bool = True,
                 iv_out: torch.Tensor | None = None, flags_out: torch.Tensor | None = None,
                 ratio_out: torch.Tensor | None = None):

@@ -161,6 +161,18 @@ int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, in
     return afiv_launch_arb_check(g->v, iv, ratio, N, spot, bs_form, flags_out, mask_out, as_stream(stream));
 }
 
+int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N, double spot, int variant,
+                             double *iv_out, int32_t *flags_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (N == 0) return AFIV_OK;
+    if (!ratio || !iv_out || !flags_out) return AFIV_E_NULL;
+    return afiv_launch_surface_iv(g->v, ratio, N, spot, variant, iv_out, flags_out, as_stream(stream));
+}
+
 int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
                  double *ratio_out, double *iv_out, int32_t *flags_out, void *stream)
 {
@@ -174,17 +186,15 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
     const int64_t per = (int64_t)g->v.nT * g->v.nK;
     if (ratio_out) {
         if ((rc = afiv_launch_price(g->v, params, N, ratio_out, s))) return rc;
-        if ((rc = afiv_launch_implied_vol(g->v, ratio_out, N, spot, variant, iv_out, s))) return rc;
-        return afiv_launch_arb_check(g->v, iv_out, ratio_out, N, spot, variant, flags_out, nullptr, s);
+        return afiv_launch_surface_iv(g->v, ratio_out, N, spot, variant, iv_out, flags_out, s);
     }
     if (!g->workspace) return AFIV_E_WORKSPACE;
     // Stream order makes the reuse of the workspace by consecutive chunks safe.
     for (int64_t off = 0; off < N; off += g->workspace_surfaces) {
         const int64_t n = (N - off < g->workspace_surfaces) ? N - off : g->workspace_surfaces;
         if ((rc = afiv_launch_price(g->v, params + 5 * off, n, g->workspace, s))) return rc;
-        if ((rc = afiv_launch_implied_vol(g->v, g->workspace, n, spot, variant, iv_out + off * per, s))) return rc;
-        if ((rc = afiv_launch_arb_check(g->v, iv_out + off * per, g->workspace, n, spot, variant,
-                                        flags_out + 4 * off, nullptr, s))) return rc;
+        if ((rc = afiv_launch_surface_iv(g->v, g->workspace, n, spot, variant, iv_out + off * per,
+                                         flags_out + 4 * off, s))) return rc;
     }
     return AFIV_OK;
 }

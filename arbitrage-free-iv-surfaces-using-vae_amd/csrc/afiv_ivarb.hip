@@ -11,6 +11,7 @@
 //                 lands on the same root.
 //   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
 #include "afiv_internal.h"
+#include "afiv_math.h"
 #include "erfcx_table.inc"
 
 namespace {
@@ -37,9 +38,9 @@ __device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ 
 {
     const double sqrth = 7.07106781186547524401E-1;
     const double x = a * sqrth;
-    const double u = fabs(x);
-    const double t = 64.0 / (1.0 + u);
-    const int seg = (int)fmin(t, 63.0);             // NaN selects a valid row; f stays NaN
+    const double u = fmin(fabs(x), 40.0);           // erfc(40) = 0 in double; also maps NaN to a finite dummy
+    const double t = 64.0 * afivm::rcp_f64(1.0 + u);
+    const int seg = (int)fmin(t, 63.0);
     const double f = (t - (double)seg) - 0.5;
     const double *c = tab + seg * ERFCX_ROW;
     double p = c[8];
@@ -51,13 +52,13 @@ __device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ 
     p = fma(p, f, c[2]);
     p = fma(p, f, c[1]);
     p = fma(p, f, c[0]);
-    const double uc = fmin(u, 40.0);                // exp(-u^2) is zero long before
-    const double s = uc * uc;
-    const double lo = fma(uc, uc, -s);              // exact low part of the square
-    double e = exp(-s);
+    const double s = u * u;
+    const double lo = fma(u, u, -s);                // exact low part of the square
+    double e = afivm::exp_f64(-s);
     e = fma(-e, lo, e);
     const double h = 0.5 * e * p;                   // erfc(|x|)/2
-    return x > 0 ? 1.0 - h : h;
+    const double r = x > 0 ? 1.0 - h : h;
+    return x != x ? x : r;                          // NaN in, NaN out
 }
 
 // Per-point constants of the Black-Scholes objective.
@@ -90,8 +91,9 @@ __device__ __forceinline__ double bs_price(const BsPoint &c, double iv, const do
 // scipy/optimize/Zeros/brentq.c with the Python wrapper's NaN check; NaN on any failure.
 template <int VARIANT>
 __device__ double brentq_dev(const BsPoint &c, const double *__restrict__ tab, double xa, double xb,
-                             double xtol, double rtol, int maxiter)
+                             double xtol, double rtol, int maxiter, double *f_at_root)
 {
+    *f_at_root = 0.0;
     double xpre = xa, xcur = xb, xblk = 0.0, fpre, fcur, fblk = 0.0, spre = 0.0, scur = 0.0;
     double sbis, delta, stry, dpre, dblk;
     const double nan = __builtin_nan("");
@@ -102,6 +104,8 @@ __device__ double brentq_dev(const BsPoint &c, const double *__restrict__ tab, d
     if (fpre == 0) return xpre;
     if (fcur == 0) return xcur;
     if (signbit(fpre) == signbit(fcur)) return nan;
+    // value of the objective at the returned abscissa: lets a caller re-price for free
+    // (price = objective + target, exact by Sterbenz' lemma at a root)
     for (int i = 0; i < maxiter; ++i) {
         if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
             xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
@@ -112,7 +116,7 @@ __device__ double brentq_dev(const BsPoint &c, const double *__restrict__ tab, d
         }
         delta = (xtol + rtol * fabs(xcur)) / 2;
         sbis = (xblk - xcur) / 2;
-        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fcur == 0 || fabs(sbis) < delta) { *f_at_root = fcur; return xcur; }
         if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
             if (xpre == xblk) {
                 stry = -fcur * (xcur - xpre) / (fcur - fpre);
@@ -171,15 +175,15 @@ __global__ __launch_bounds__(256) void implied_vol_kernel(GridView g, const doub
         BsPoint c = make_point(g, t, k, spot);
         const double hp = pr * spot * c.disc;
         c.target = hp;
-        double iv;
+        double iv, froot;
         if (VARIANT == AFIV_VARIANT_A) {
             const double intrinsic = fmax(c.F - c.K, 0.0) * c.disc;
             if (hp < intrinsic * 0.99) iv = nan;
-            else iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+            else iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100, &froot);
         } else {
             if (hp < 1e-10 || isnan(pr)) iv = nan;
             else {
-                iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100);
+                iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100, &froot);
                 if (isnan(iv) || iv <= 0 || iv > 3.0) iv = nan;
             }
         }
@@ -278,6 +282,135 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
             flags[4 * s + 3] = status;
         }
         __syncthreads();
+    }
+}
+
+// Fused implied vol + checks, one workgroup per surface.
+//
+// Lane order is strike-major (consecutive lanes walk the maturities of one strike): Brent's
+// iteration count depends mostly on moneyness (7 iterations at the money, 15 deep in the money),
+// so a wave that holds ~3 adjacent strikes finishes together instead of waiting for its slowest
+// lane.  Ratios are staged through LDS so that global reads and writes stay coalesced; the
+// per-point constants (log F/K, ...) are computed once per workgroup.  With CHECKS the
+// re-priced Black-Scholes value of each vol is taken from Brent's last objective value
+// (objective + target, exact at a root), so the checks cost no further normal CDFs.
+struct PointTable { double lnFK, K, F, kdr, sdq; };
+
+template <int VARIANT, bool CHECKS>
+__global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *__restrict__ ratio, int64_t N,
+                                                      double spot, double *__restrict__ iv_out,
+                                                      int32_t *__restrict__ flags)
+{
+    extern __shared__ double dyn[];
+    const int nT = g.nT, nK = g.nK, per = nT * nK;
+    double *tab = dyn;                          // ERFCX_LDS
+    double *pr = tab + ERFCX_LDS;               // [per] ratios of the current surface
+    double *ivs = pr + per;                     // [per]
+    double *price = ivs + per;                  // [per]
+    double *lnfk = price + per;                 // [per] log(F/K) (variant A)
+    __shared__ int skip_t[AFIV_MAX_MATURITIES];
+    __shared__ int counters[5];
+    const int tid = threadIdx.x;
+    load_erfcx_table(tab);
+    for (int i = tid; i < per; i += 256) {
+        const int t = i / nK, k = i - t * nK;
+        lnfk[i] = log((spot * g.fwd_mult[t]) / (spot * g.Kmult[k]));
+    }
+    const double nan = __builtin_nan("");
+    for (int64_t s = blockIdx.x; s < N; s += gridDim.x) {
+        __syncthreads();
+        if (tid < 5) counters[tid] = 0;
+        if (tid < AFIV_MAX_MATURITIES) skip_t[tid] = 0;
+        for (int i = tid; i < per; i += 256) pr[i] = ratio[s * per + i];
+        __syncthreads();
+        int n_nan = 0, n_bad = 0;
+        for (int j = tid; j < per; j += 256) {
+            const int k = j / nT, t = j - k * nT;
+            const int i = t * nK + k;
+            BsPoint c;
+            c.tau = g.tau[t];
+            c.sqrt_tau = sqrt(c.tau);
+            c.disc = g.disc_tau[t];
+            c.K = spot * g.Kmult[k];
+            c.F = spot * g.fwd_mult[t];
+            c.lnFK = lnfk[i];
+            c.sdq = spot * g.dq_tau[t];
+            c.kdr = c.K * c.disc;
+            c.logm = g.logm[k];
+            c.rq = g.r - g.q;
+            const double y = pr[i];
+            const double hp = y * spot * c.disc;
+            c.target = hp;
+            double iv, froot = 0.0;
+            if (VARIANT == AFIV_VARIANT_A) {
+                const double intrinsic = fmax(c.F - c.K, 0.0) * c.disc;
+                if (hp < intrinsic * 0.99) iv = nan;
+                else iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100, &froot);
+            } else {
+                if (hp < 1e-10 || isnan(y)) iv = nan;
+                else {
+                    iv = brentq_dev<VARIANT>(c, tab, 0.001, 3.0, 1e-6, 4 * 2.220446049250313e-16, 100, &froot);
+                    if (isnan(iv) || iv <= 0 || iv > 3.0) iv = nan;
+                }
+            }
+            ivs[i] = iv;
+            if (CHECKS) {
+                price[i] = froot + hp;
+                if (isnan(iv)) { n_nan++; n_bad++; }
+                else if (iv <= 0) n_bad++;
+                if (isnan(y) || y < 0) skip_t[t] = 1;          // benign race: all writers store 1
+            }
+        }
+        if (CHECKS) {
+            n_nan = wave_sum(n_nan);
+            n_bad = wave_sum(n_bad);
+            if ((tid & 63) == 0) {
+                if (n_nan) atomicAdd(&counters[0], n_nan);
+                if (n_bad) atomicAdd(&counters[1], n_bad);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < per; i += 256) iv_out[s * per + i] = ivs[i];
+        if (CHECKS) {
+            int n_stat = 0, n_cal = 0, n_fly = 0;
+            const bool valid = counters[1] == 0;
+            for (int i = tid; i < per; i += 256) {
+                const int t = i / nK, k = i - t * nK;
+                if (valid) {
+                    if (k + 1 < nK && price[i] < price[i + 1] - 1e-6) n_stat++;
+                    if (t + 1 < nT && price[i] > price[i + nK] + 1e-6) n_cal++;
+                }
+                if (k + 2 < nK && !skip_t[t]) {
+                    const double b = pr[i] - 2 * pr[i + 1] + pr[i + 2];
+                    if (b < 0) n_fly++;
+                }
+            }
+            n_stat = wave_sum(n_stat);
+            n_cal = wave_sum(n_cal);
+            n_fly = wave_sum(n_fly);
+            if ((tid & 63) == 0) {
+                if (n_stat) atomicAdd(&counters[2], n_stat);
+                if (n_cal) atomicAdd(&counters[3], n_cal);
+                if (n_fly) atomicAdd(&counters[4], n_fly);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int nn = counters[0];
+                const int st = valid ? counters[2] : -1;
+                const int ca = valid ? counters[3] : -1;
+                const int fl = counters[4];
+                int status = 0;
+                if (valid && st == 0 && ca == 0) status |= 1;
+                if (fl == 0) status |= 2;
+                if (valid) status |= 4;
+                if ((double)nn / (double)per < 0.1) status |= 8;
+                if (nn == 0) status |= 16;
+                flags[4 * s + 0] = st;
+                flags[4 * s + 1] = ca;
+                flags[4 * s + 2] = fl;
+                flags[4 * s + 3] = status;
+            }
+        }
     }
 }
 
@@ -382,10 +515,42 @@ int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t 
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+namespace {
+template <int VARIANT, bool CHECKS>
+int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
+                          int32_t *flags, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * ((size_t)ERFCX_LDS + 4 * (size_t)g.nT * g.nK);
+    if (lds > 48 * 1024) {
+        // raising the dynamic-LDS limit is a per-function attribute, not an allocation
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+    }
+    const int64_t blocks = N < 256 * 64 ? N : 256 * 64;
+    hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS>), dim3((unsigned)blocks), dim3(256), lds, s, g, ratio, N,
+                       spot, iv_out, flags);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+}  // namespace
+
+// implied vols and (flags != nullptr) the checks in one pass; bs form of the checks = variant
+int afiv_launch_surface_iv(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
+                           double *iv_out, int32_t *flags, hipStream_t s)
+{
+    if (N <= 0) return 0;
+    if (variant == 0)
+        return flags ? launch_surface_kernel<0, true>(g, ratio, N, spot, iv_out, flags, s)
+                     : launch_surface_kernel<0, false>(g, ratio, N, spot, iv_out, flags, s);
+    return flags ? launch_surface_kernel<1, true>(g, ratio, N, spot, iv_out, flags, s)
+                 : launch_surface_kernel<1, false>(g, ratio, N, spot, iv_out, flags, s);
+}
+
 int afiv_launch_implied_vol(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
                             double *iv_out, hipStream_t s)
 {
     if (N <= 0) return 0;
+    return afiv_launch_surface_iv(g, ratio, N, spot, variant, iv_out, nullptr, s);
     const int64_t total = N * g.nT * g.nK;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -96,6 +96,14 @@ int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double 
 int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, int64_t N,
                    double spot, int bs_form, int32_t *flags_out, uint8_t *mask_out, void *stream);
 
+/* ---- implied vol and checks in one pass over the lattice: afiv_implied_vol followed by
+ * afiv_arb_check(bs_form = variant, no mask) with identical results, but each vol's re-priced
+ * Black-Scholes value is taken from the root finder's last objective evaluation instead of being
+ * recomputed.  Replaces the body of generate_iv_surface plus check_all_arbitrage
+ * (generate_regime_surfaces.py:320-335 calls them back to back). */
+int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N, double spot,
+                             int variant, double *iv_out, int32_t *flags_out, void *stream);
+
 /* ---- whole surface: price -> implied vol -> checks for N parameter sets, i.e. the body of the
  * per-sample loop generate_iv_surface_by_date.py:464-468 plus the checks above.
  * ratio_out may be NULL if the grid has a workspace (the batch is then processed in

@@ -251,6 +251,36 @@ def test_surface_end_to_end_matches_oracle(afiv, grid821):
     assert np.mean((flags[:, 3] & 8) == (flags_r[:, 3] & 8)) > 0.97
 
 
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_fused_iv_and_checks_equal_the_two_separate_passes(afiv, grid821, variant):
+    p = sample_params(300, 17)
+    ratio = grid821.price(dev(p))
+    rng = np.random.default_rng(3)
+    noisy = ratio.clone()
+    noisy[::4] += torch.as_tensor(1e-4 * rng.standard_normal(tuple(noisy[::4].shape)), device="cuda")
+    noisy[5, 2, 3] = float("nan")
+    iv1 = grid821.implied_vol(noisy, SPOT, variant)
+    fl1 = grid821.arb_check(iv1, noisy, SPOT, variant)
+    iv2, fl2 = grid821.implied_vol_checked(noisy, SPOT, variant)
+    assert torch.equal(torch.nan_to_num(iv1, nan=-1.0), torch.nan_to_num(iv2, nan=-1.0))
+    assert torch.equal(fl1, fl2)
+    assert (fl1[:, 0] > 0).any() and (fl1[:, 2] > 0).any() and (fl1[:, 0] < 0).any()
+
+
+def test_fused_kernel_on_the_largest_lattice(afiv):
+    logm = np.linspace(-0.3, 0.3, 64)
+    tau = np.linspace(0.05, 3.0, 64)
+    grid = afiv.Grid(logm, tau, R, Q)
+    p = sample_params(9, 4)
+    iv, flags, ratio = grid.surface(dev(p), SPOT, "A")
+    ref_ratio = oracle.price_ratio_grid(p, logm, tau, R, Q)
+    assert np.all(np.abs(ratio.cpu().numpy() - ref_ratio) <= price_tol(ref_ratio, p))
+    iv_o = oracle.implied_vol_grid(ratio.cpu().numpy(), logm, tau, SPOT, R, Q, "A")
+    assert_iv_close(iv.cpu().numpy(), iv_o, logm, tau, SPOT, R, Q)
+    flags_o = oracle.arb_check(iv.cpu().numpy(), ratio.cpu().numpy(), logm, tau, SPOT, R, Q, "A")
+    assert np.array_equal(flags.cpu().numpy(), flags_o)
+
+
 def test_surface_workspace_chunks_equal_direct(afiv):
     grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q, workspace_surfaces=7)
     p = dev(sample_params(40, 2))
