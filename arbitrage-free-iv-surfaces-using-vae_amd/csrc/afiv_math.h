@@ -21,6 +21,42 @@
 
 namespace afivm {
 
+// Polynomial coefficients live in constant memory and are fetched where they are used, with scalar
+// loads, so that the FMAs read them as scalar operands.  f64 instructions take no 64-bit literal:
+// written as literals each coefficient would be copied into a vector register pair, and hoisted
+// out of the kernels' loops those 45 pairs (or, hoisted as scalars, 90 scalar registers) end up
+// spilled.  coeffs() hands out the table's address through an empty asm statement that names a
+// value the caller has just computed: the compiler cannot prove the address loop-invariant, nor
+// move the loads above that value, so each polynomial's coefficients are live only around it.
+#define AFIV_C6(P) P##0, P##1, P##2, P##3, P##4, P##5
+enum { OFF_SIN = 0, OFF_COS = 6, OFF_LOG = 12, OFF_ATAN = 20, OFF_EXP = 32, N_COEF = 48 };
+inline __constant__ __attribute__((aligned(64))) double c_tab[N_COEF] = {
+    AFIV_C6(AFIV_SIN_C), AFIV_C6(AFIV_COS_C),
+    AFIV_C6(AFIV_LOG_C), AFIV_LOG_C6, 0.0,
+    AFIV_C6(AFIV_ATAN_C), AFIV_ATAN_C6, AFIV_ATAN_C7, AFIV_ATAN_C8, AFIV_ATAN_C9, AFIV_ATAN_C10, AFIV_ATAN_C11,
+    AFIV_C6(AFIV_EXP_C), AFIV_EXP_C6, AFIV_EXP_C7, AFIV_EXP_C8, AFIV_EXP_C9, AFIV_EXP_C10, AFIV_EXP_C11,
+    AFIV_EXP_C12, AFIV_EXP_C13, 0.0, 0.0};
+
+typedef const double __attribute__((address_space(4))) *coef_ptr;
+
+__device__ __forceinline__ coef_ptr coeffs(double after)
+{
+    unsigned long long a = (unsigned long long)(const void *)c_tab;
+    asm volatile("" : "+s"(a) : "v"(after));
+    return (coef_ptr)a;
+}
+
+
+// p z + c with the coefficient read straight from its scalar register pair.  (Left to itself the
+// compiler copies a coefficient that arrives as part of a wide scalar load into a vector register
+// pair first: two extra instructions per Horner step.)
+__device__ __forceinline__ double fma_sc(double p, double z, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(z), "s"(c));
+    return d;
+}
+
 __device__ __forceinline__ double rcp_f64(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -36,18 +72,19 @@ __device__ __forceinline__ double exp_f64(double x)
     const double k = __builtin_rint(xc * AFIV_LOG2E);
     double r = __builtin_fma(k, -AFIV_LN2_HI, xc);
     r = __builtin_fma(k, -AFIV_LN2_LO, r);
-    double p = AFIV_EXP_C13;
-    p = __builtin_fma(p, r, AFIV_EXP_C12);
-    p = __builtin_fma(p, r, AFIV_EXP_C11);
-    p = __builtin_fma(p, r, AFIV_EXP_C10);
-    p = __builtin_fma(p, r, AFIV_EXP_C9);
-    p = __builtin_fma(p, r, AFIV_EXP_C8);
-    p = __builtin_fma(p, r, AFIV_EXP_C7);
-    p = __builtin_fma(p, r, AFIV_EXP_C6);
-    p = __builtin_fma(p, r, AFIV_EXP_C5);
-    p = __builtin_fma(p, r, AFIV_EXP_C4);
-    p = __builtin_fma(p, r, AFIV_EXP_C3);
-    p = __builtin_fma(p, r, AFIV_EXP_C2);
+    const coef_ptr c_exp = coeffs(r) + OFF_EXP;
+    double p = c_exp[13];
+    p = fma_sc(p, r, c_exp[12]);
+    p = fma_sc(p, r, c_exp[11]);
+    p = fma_sc(p, r, c_exp[10]);
+    p = fma_sc(p, r, c_exp[9]);
+    p = fma_sc(p, r, c_exp[8]);
+    p = fma_sc(p, r, c_exp[7]);
+    p = fma_sc(p, r, c_exp[6]);
+    p = fma_sc(p, r, c_exp[5]);
+    p = fma_sc(p, r, c_exp[4]);
+    p = fma_sc(p, r, c_exp[3]);
+    p = fma_sc(p, r, c_exp[2]);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     const double y = __builtin_ldexp(p, (int)k);                // v_ldexp_f64: exact scaling, graceful under/overflow
@@ -63,19 +100,21 @@ __device__ __forceinline__ void sincos_f64(double x, double *s_out, double *c_ou
     r = __builtin_fma(k, -AFIV_PIO2_3, r);
     const int q = (int)k;
     const double z = r * r;
-    double ps = AFIV_SIN_C5;
-    ps = __builtin_fma(ps, z, AFIV_SIN_C4);
-    ps = __builtin_fma(ps, z, AFIV_SIN_C3);
-    ps = __builtin_fma(ps, z, AFIV_SIN_C2);
-    ps = __builtin_fma(ps, z, AFIV_SIN_C1);
-    ps = __builtin_fma(ps, z, AFIV_SIN_C0);
+    const coef_ptr c_sin = coeffs(z) + OFF_SIN;
+    const coef_ptr c_cos = c_sin + (OFF_COS - OFF_SIN);
+    double ps = c_sin[5];
+    ps = fma_sc(ps, z, c_sin[4]);
+    ps = fma_sc(ps, z, c_sin[3]);
+    ps = fma_sc(ps, z, c_sin[2]);
+    ps = fma_sc(ps, z, c_sin[1]);
+    ps = fma_sc(ps, z, c_sin[0]);
     const double sn = __builtin_fma(r * z, ps, r);
-    double pc = AFIV_COS_C5;
-    pc = __builtin_fma(pc, z, AFIV_COS_C4);
-    pc = __builtin_fma(pc, z, AFIV_COS_C3);
-    pc = __builtin_fma(pc, z, AFIV_COS_C2);
-    pc = __builtin_fma(pc, z, AFIV_COS_C1);
-    pc = __builtin_fma(pc, z, AFIV_COS_C0);
+    double pc = c_cos[5];
+    pc = fma_sc(pc, z, c_cos[4]);
+    pc = fma_sc(pc, z, c_cos[3]);
+    pc = fma_sc(pc, z, c_cos[2]);
+    pc = fma_sc(pc, z, c_cos[1]);
+    pc = fma_sc(pc, z, c_cos[0]);
     const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     // quadrant: x = r + q pi/2
     const bool swap = q & 1;
@@ -106,13 +145,14 @@ __device__ __forceinline__ double log1p_f64(double f)
     const double g = small ? f : __builtin_fma(c, scale, m - 1.0);
     const double s = g * rcp_f64(2.0 + g);
     const double z = s * s;
-    double p = AFIV_LOG_C6;
-    p = __builtin_fma(p, z, AFIV_LOG_C5);
-    p = __builtin_fma(p, z, AFIV_LOG_C4);
-    p = __builtin_fma(p, z, AFIV_LOG_C3);
-    p = __builtin_fma(p, z, AFIV_LOG_C2);
-    p = __builtin_fma(p, z, AFIV_LOG_C1);
-    p = __builtin_fma(p, z, AFIV_LOG_C0);
+    const coef_ptr c_log = coeffs(z) + OFF_LOG;
+    double p = c_log[6];
+    p = fma_sc(p, z, c_log[5]);
+    p = fma_sc(p, z, c_log[4]);
+    p = fma_sc(p, z, c_log[3]);
+    p = fma_sc(p, z, c_log[2]);
+    p = fma_sc(p, z, c_log[1]);
+    p = fma_sc(p, z, c_log[0]);
     // log(1+g) = 2 atanh(s) = 2 s + s z P(z) = g - s (g - z P(z))
     const double lg = g - s * (g - z * p);
     const double ed = (double)e;
@@ -130,18 +170,19 @@ __device__ __forceinline__ double atan2_f64(double y, double x)
     const double den = hi ? mn + mx : mx;
     const double t = num * rcp_f64(den);
     const double z = t * t;
-    double p = AFIV_ATAN_C11;
-    p = __builtin_fma(p, z, AFIV_ATAN_C10);
-    p = __builtin_fma(p, z, AFIV_ATAN_C9);
-    p = __builtin_fma(p, z, AFIV_ATAN_C8);
-    p = __builtin_fma(p, z, AFIV_ATAN_C7);
-    p = __builtin_fma(p, z, AFIV_ATAN_C6);
-    p = __builtin_fma(p, z, AFIV_ATAN_C5);
-    p = __builtin_fma(p, z, AFIV_ATAN_C4);
-    p = __builtin_fma(p, z, AFIV_ATAN_C3);
-    p = __builtin_fma(p, z, AFIV_ATAN_C2);
-    p = __builtin_fma(p, z, AFIV_ATAN_C1);
-    p = __builtin_fma(p, z, AFIV_ATAN_C0);
+    const coef_ptr c_atan = coeffs(z) + OFF_ATAN;
+    double p = c_atan[11];
+    p = fma_sc(p, z, c_atan[10]);
+    p = fma_sc(p, z, c_atan[9]);
+    p = fma_sc(p, z, c_atan[8]);
+    p = fma_sc(p, z, c_atan[7]);
+    p = fma_sc(p, z, c_atan[6]);
+    p = fma_sc(p, z, c_atan[5]);
+    p = fma_sc(p, z, c_atan[4]);
+    p = fma_sc(p, z, c_atan[3]);
+    p = fma_sc(p, z, c_atan[2]);
+    p = fma_sc(p, z, c_atan[1]);
+    p = fma_sc(p, z, c_atan[0]);
     double a = __builtin_fma(t * z, p, t);                      // atan of the reduced argument
     a = hi ? a + AFIV_PIO4 : a;                                 // angle of (mx, mn) in [0, pi/4]
     a = ay > ax ? 2.0 * AFIV_PIO4 - a : a;                      // first octant pair

@@ -14,17 +14,18 @@
 // a [rows x 576] x [576 x strikes] FP64 contraction against strike tables that depend only on the
 // grid (phase 2, v_mfma_f64_16x16x4_f64).
 //
-// Work decomposition: one workgroup = 5 surfaces x 144 Laguerre nodes = 720 of 768 threads =
-// 12 waves, i.e. 3 per SIMD (balanced); a thread owns one node of one surface and evaluates both
-// integrals j = 1, 2.  Maturity-independent quantities (d, t1-d, p, 1/(1-p)) stay in registers.
-// The workgroup advances in steps of 3 maturities: 5 surfaces x 3 maturities fill 15 of the 16
-// rows of one MFMA row block.  Phase 1 of step G writes its 16 x 576 operand block into one half
-// of a double-buffered LDS area while phase 2 of step G-1 reads the other half: each wave owns
-// one (column tile, K range) of the contraction and issues its MFMA chain after a different one
-// of the step's six characteristic-function evaluations (waves w, w+4, w+8 share a SIMD), so
-// the matrix pipe works in the shadow of the other waves' vector work.  B fragments stream
-// from the L2-resident table; partial tiles are reduced through LDS in a fixed order (bitwise
-// reproducible results).
+// Work decomposition: one workgroup = 7 surfaces x 144 Laguerre nodes = 1008 of 1024 threads =
+// 16 waves, 4 per SIMD; a thread owns one node of one surface and evaluates both integrals
+// j = 1, 2.  Maturity-independent quantities (d, t1-d, p, 1/(1-p)) stay in registers.  The
+// workgroup advances in steps of 2 maturities: 7 surfaces x 2 maturities fill 14 of the 16 rows
+// of one MFMA row block.  Phase 1 of step G writes its 16 x 576 operand block into one half of a
+// double-buffered LDS area while phase 2 of step G-1 reads the other half: each wave owns one
+// (column tile, K range) of the contraction and issues its MFMA chain after a different one of
+// the step's four characteristic-function evaluations (waves w, w+4, w+8, w+12 share a SIMD), so
+// the chain's table loads and LDS reads are covered by the other waves' vector work.  B
+// fragments stream from the L2-resident table through raw buffer loads (one offset register
+// instead of a 64-bit address pair per fragment), two batches in flight; partial tiles are
+// reduced through LDS in a fixed order (bitwise reproducible results).
 #include "afiv_internal.h"
 #include "afiv_math.h"
 #include "laguerre144.inc"
@@ -33,14 +34,14 @@ namespace {
 
 constexpr int NQ = AFIV_NQ_NODES;          // 144
 constexpr int KDIM = AFIV_KDIM;            // 576
-// Workgroup shape.  5 surfaces x 144 nodes = 720 of 768 lanes (12 waves, 3 per SIMD, <= 168
-// VGPRs without spilling); 5 surfaces x 3 maturities fill 15 of the 16 MFMA rows.  Measured
-// alternatives on MI355X (20 x 50 lattice, 131 072 surfaces): 3 x 512 / 5 maturities 14.1 ms,
-// 5 x 768 / 3 maturities 13.3 ms, 7 x 1024 / 2 maturities 24.3 ms (128-VGPR cap -> scratch spills).
+// Workgroup shape.  The kernel needs <= 128 VGPRs for 16 waves per CU; it uses about 115 because
+// polynomial coefficients are scalar operands fetched next to their use (afiv_math.h) and table
+// addresses are buffer offsets.  Measured on MI355X (20 x 50 lattice, 131 072 surfaces):
+// 3 surfaces x 512 threads / 5 maturities per step 15.5 ms, 5 x 768 / 3 12.6 ms, 7 x 1024 / 2 11.5 ms.
 #ifndef AFIV_SPB
-#define AFIV_SPB 5
-#define AFIV_THREADS 768
-#define AFIV_MT 3
+#define AFIV_SPB 7
+#define AFIV_THREADS 1024
+#define AFIV_MT 2
 #endif
 constexpr int SPB = AFIV_SPB;              // surfaces per workgroup
 constexpr int THREADS = AFIV_THREADS;
@@ -77,6 +78,20 @@ __device__ __forceinline__ Cx csqrt_principal(Cx z)
         d.i = copysign(t, z.i);
     }
     return d;
+}
+
+// Largest batch of table loads (<= 12) that cuts n k-steps into one batch or an even number of them.
+constexpr int pick_batch(int n)
+{
+    for (int nb = 12; nb >= 1; --nb)
+        if (n % nb == 0 && (n / nb == 1 || (n / nb) % 2 == 0)) return nb;
+    return 1;
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ldtab(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
 
 // Maturity-independent part of A_j(phi) for one integral.
@@ -172,14 +187,16 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     __shared__ double lds[2 * XBUF];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
     const int sl = tid / NQ;                  // < SPB: real surfaces; == SPB: spare lanes of the last wave
     const int n = tid - sl * NQ;
     const double phi = c_lag_x[n];
     const double wp = c_lag_wp[n];
     const int ct = wave % NCTP, kq = wave / NCTP;
-    // waves w, w+4, ... share a SIMD: they issue their MFMA chain after different evaluations
-    const int my_eval = (wave >> 2) * (NEVAL / (WAVES / 4));
+    // waves w, w+4, ... share a SIMD: each issues its MFMA chain after a different one of the
+    // step's 2*MT characteristic-function evaluations
+    const int my_slot = (wave >> 2) * (NEVAL / (WAVES / 4));
+    static_assert(NEVAL >= WAVES / 4, "one distinct MFMA slot per wave of a SIMD");
     const int nT = g.nT, nK = g.nK, nKpad = g.nKpad;
     const bool ct_live = 16 * ct < nKpad;
     const int ntiles = (nT + MT - 1) / MT;
@@ -213,28 +230,71 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         }
 
         v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const bool do_mfma = have_prev && ct_live;
+        auto mfma_chain = [&]() {
+            // [16 x KLEN] x [KLEN x 16] on the matrix pipe.  B fragments come from the
+            // L2-resident table: they are fetched a batch ahead so that the MFMA chain
+            // never waits on a load it has just issued.
+            constexpr int NSTEP = KLEN / 4;
+            constexpr int NB = pick_batch(NSTEP);                  // table loads in flight per batch
+            constexpr int NPAIR = NSTEP / (2 * NB);                // 0: a single batch
+            static_assert(NB * (NPAIR ? 2 * NPAIR : 1) == NSTEP, "one batch or pairs of batches");
+            const double *xa = xr + (lane & 15) * XSTRIDE + kq * KLEN + (lane >> 4);
+            // Table fragments through a buffer resource: one 32-bit per-lane offset plus a
+            // scalar offset per load (plain pointers cost a 64-bit address register pair per
+            // load here).  Reads past the table return 0.
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double *>(g.tab), 0, KDIM * nKpad * (int)sizeof(double), 0x00020000);
+            const unsigned lo = (unsigned)(((kq * KLEN + (lane >> 4)) * nKpad + 16 * ct + (lane & 15)) * 8);
+            const unsigned kstride = (unsigned)(4 * nKpad * 8);     // bytes per MFMA k-step
+            double b0[NB], b1[NB];
 #pragma unroll
-        for (int e = 0; e < NEVAL; ++e) {
-            if (have_cur) {
-                const int tl = e >> 1;
-                const int t = tile * MT + tl;
-                double2 x = make_double2(0.0, 0.0);
-                if (t < nT) {
-                    const double T = g.term[t], ddt = g.dd[t];
-                    x = (e & 1) == 0 ? cf_eval(st0, m, phi, wp, T, ddt, g.Dq[t])
-                                     : cf_eval(st1, m, phi, wp, T, ddt, g.Dr[t]);
+            for (int i = 0; i < NB; ++i) b0[i] = ldtab(rs, lo, kstride * i);
+            if (NPAIR == 0) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * i], b0[i], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int base = 2 * pr * NB;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) b1[i] = ldtab(rs, lo, kstride * (base + NB + i));
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * (base + i)], b0[i], acc, 0, 0, 0);
+                if (pr + 1 < NPAIR) {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) b0[i] = ldtab(rs, lo, kstride * (base + 2 * NB + i));
                 }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * (base + NB + i)], b1[i], acc, 0, 0, 0);
+            }
+        };
+        // per-maturity constants (wave-uniform -> scalar registers), fetched one maturity ahead
+        int tn = min(tile * MT, nT - 1);
+        double Tn = g.term[tn], ddn = g.dd[tn], Dqn = g.Dq[tn], Drn = g.Dr[tn];
+#pragma unroll 1
+        for (int tl = 0; tl < MT; ++tl) {
+            const double T = Tn, ddt = ddn, Dq = Dqn, Dr = Drn;
+            const int t = tile * MT + tl;
+            tn = min(t + 1, nT - 1);
+            Tn = g.term[tn]; ddn = g.dd[tn]; Dqn = g.Dq[tn]; Drn = g.Dr[tn];
+            if (have_cur) {
+                double2 x0 = make_double2(0.0, 0.0);
+                if (t < nT) x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq);
                 if (sl < SPB)     // spare lanes of the last wave own no row
-                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * ((e & 1) * NQ + n)]) = x;
+                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * n]) = x0;
             }
-            if (have_prev && e == my_eval && ct_live) {
-                // [16 x KLEN] x [KLEN x 16] on the matrix pipe
-                const double *xa = xr + (lane & 15) * XSTRIDE + kq * KLEN + (lane >> 4);
-                const double *tb = g.tab + (size_t)(kq * KLEN + (lane >> 4)) * nKpad + 16 * ct + (lane & 15);
-#pragma unroll 6
-                for (int ks = 0; ks < KLEN / 4; ++ks)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * ks], tb[(size_t)(4 * ks) * nKpad], acc, 0, 0, 0);
+            if (do_mfma && 2 * tl == my_slot) mfma_chain();
+            if (have_cur) {
+                double2 x1 = make_double2(0.0, 0.0);
+                if (t < nT) x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr);
+                if (sl < SPB)
+                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * (NQ + n)]) = x1;
             }
+            if (do_mfma && 2 * tl + 1 == my_slot) mfma_chain();
         }
         __syncthreads();          // operand block G complete; every MFMA chain of step G-1 done
         if (have_prev && ct_live) {
