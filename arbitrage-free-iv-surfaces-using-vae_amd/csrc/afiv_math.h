@@ -46,6 +46,13 @@ __device__ __forceinline__ coef_ptr coeffs(double after)
     return (coef_ptr)a;
 }
 
+// The same table without the pinning: for kernels with scalar registers to spare, where the
+// compiler may load the coefficients once, outside the loops.
+__device__ __forceinline__ coef_ptr coeffs_hoistable()
+{
+    return (coef_ptr)(unsigned long long)(const void *)c_tab;
+}
+
 
 // p z + c with the coefficient read straight from its scalar register pair.  (Left to itself the
 // compiler copies a coefficient that arrives as part of a wide scalar load into a vector register
@@ -66,13 +73,14 @@ __device__ __forceinline__ double rcp_f64(double x)
     return __builtin_fma(r, e, r);
 }
 
+template <bool PINNED = true>
 __device__ __forceinline__ double exp_f64(double x)
 {
     const double xc = fmin(fmax(x, -1000.0), 1000.0);          // keeps k inside int range; NaN -> finite garbage is avoided below
     const double k = __builtin_rint(xc * AFIV_LOG2E);
     double r = __builtin_fma(k, -AFIV_LN2_HI, xc);
     r = __builtin_fma(k, -AFIV_LN2_LO, r);
-    const coef_ptr c_exp = coeffs(r) + OFF_EXP;
+    const coef_ptr c_exp = (PINNED ? coeffs(r) : coeffs_hoistable()) + OFF_EXP;
     double p = c_exp[13];
     p = fma_sc(p, r, c_exp[12]);
     p = fma_sc(p, r, c_exp[11]);
