@@ -53,7 +53,9 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
 
     // Host-side constants use the host libm so that discount factors, forwards and strikes are
     // the very doubles NumPy produces in the Python reference.
-    const size_t nd = (size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad;
+    const size_t n_point = (size_t)4 * nT * nK;     // device-written table, kept 32-byte aligned
+    const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + 3) / 4 * 4;
+    const size_t nd = n_const + n_point;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
            *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
@@ -114,6 +116,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     v.tau = dev; v.term = v.tau + nT; v.dd = v.term + nT; v.Dq = v.dd + nT; v.Dr = v.Dq + nT;
     v.disc_tau = v.Dr + nT; v.fwd_mult = v.disc_tau + nT; v.dq_tau = v.fwd_mult + nT;
     v.logm = v.dq_tau + nT; v.Kmult = v.logm + nK; v.tab = v.Kmult + nK;
+    v.point = dev + n_const;
     *out = g;
     return AFIV_OK;
 }

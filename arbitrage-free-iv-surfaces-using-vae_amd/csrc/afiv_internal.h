@@ -25,6 +25,10 @@ struct GridView {
     const double *logm;       // [nK]
     const double *Kmult;      // [nK] exp(logm)
     const double *tab;        // [AFIV_KDIM][nKpad] strike tables, see afiv_price.hip
+    double *point;            // [nT*nK][4] per-call table of the implied-vol kernel (log F/K and the
+                              // Black-Scholes values at the bracket ends for the call's spot);
+                              // rewritten by every implied-vol call, so calls on one grid must
+                              // not overlap
 };
 
 struct afiv_grid {

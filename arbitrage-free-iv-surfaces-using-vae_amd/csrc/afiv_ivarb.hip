@@ -55,7 +55,7 @@ __device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ 
     p = fma(p, f, c[0]);
     const double s = u * u;
     const double lo = fma(u, u, -s);                // exact low part of the square
-    double e = afivm::exp_f64<false>(-s);
+    double e = NANSAFE ? afivm::exp_f64<false>(-s) : afivm::exp_core_f64<false>(-s);   // s <= 1600
     e = fma(-e, lo, e);
     const double h = 0.5 * e * p;                   // erfc(|x|)/2
     const double r = x > 0 ? 1.0 - h : h;
@@ -176,6 +176,9 @@ __device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, d
 
 // One workgroup per surface.
 constexpr int ARB_THREADS = 256;
+#ifndef AFIV_IV_THREADS
+#define AFIV_IV_THREADS 512               // fused kernel, wave-per-surface mode: 8 surfaces in flight per workgroup
+#endif
 constexpr int MAX_PTS = AFIV_MAX_STRIKES * AFIV_MAX_MATURITIES;
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -270,24 +273,50 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
 
 // Fused implied vol + checks.
 //
-// A group of GT threads owns one surface at a time: one wave (GT = 64, four surfaces per
-// workgroup, no workgroup barriers in the main loop) when there are surfaces enough to fill the
-// chip, the whole workgroup (GT = 256) for small batches and for lattices whose LDS footprint
-// allows only one surface per workgroup.
+// A group of GT threads owns one surface at a time: one wave (GT = 64, no workgroup barriers in
+// the main loop) when there are surfaces enough to fill the chip, the whole workgroup otherwise
+// (small batches, and lattices whose LDS footprint allows one surface per workgroup only).
 //
 // Brent's iteration count varies from 5 to 37 over a surface (7 at the money, 15 deep in the
-// money on average), so lanes do not march through a fixed set of grid points: the root finder is
-// a per-lane state machine that makes ONE objective evaluation per trip of the wave's loop, and a
-// lane whose point has converged takes the next point from the surface's queue (strike-major
-// order, deep in-the-money strikes first) in the same trip.  A wave therefore spends
-// sum(evaluations)/64 trips on a surface plus a short tail instead of sum over lane groups of the
-// slowest lane: 1.5 x fewer objective evaluations on the benchmark lattice.
+// money on average), so lanes do not march through a fixed set of grid points.  The root finder is
+// a per-lane state machine that makes ONE objective evaluation per trip of the wave's loop; a lane
+// whose point has converged takes the next point from the surface's queue (strike-major order,
+// deep in-the-money strikes first) inside the same trip, between the two halves of Brent's loop
+// body, so no lane ever idles through an evaluation while the queue has points.  The objective
+// values at the two bracket ends depend on the grid point and the spot only (minus the target):
+// a small kernel tabulates them once per call, which saves two of the ~12.7 evaluations per point.
+// A wave therefore spends sum(iterations)/64 trips on a surface plus a short tail, 1.7 x fewer
+// evaluations than lanes bound to fixed points on the benchmark lattice.
 //
 // The surface's price ratios are staged in LDS (coalesced read); the butterfly check runs on them
 // at once, and each entry is then overwritten by the Black-Scholes price of the solved vol,
 // taken from Brent's last objective value (objective + target, exact at a root), so the static
 // and calendar checks cost no further normal CDFs.  Vols go straight to global memory.
 struct MatRow { double tau, sqrt_tau, disc, F, sdq; };
+struct __attribute__((aligned(32))) PointRow { double lnfk, fa, fb, pad; };
+
+constexpr double BRENT_XA = 0.001, BRENT_XB = 3.0, BRENT_XTOL = 1e-6, BRENT_RTOL = 4 * 2.220446049250313e-16;
+constexpr int BRENT_MAXITER = 100;
+
+// Black-Scholes values at the bracket ends and log(F/K) for every grid point (one thread each).
+template <int VARIANT>
+__global__ __launch_bounds__(256) void point_table_kernel(GridView g, double spot)
+{
+    __shared__ double tab[ERFCX_LDS];
+    load_erfcx_table(tab);
+    __syncthreads();
+    const int per = g.nT * g.nK;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int t = i / g.nK, k = i - t * g.nK;
+    const BsPoint c = make_point(g, t, k, spot);
+    PointRow row;
+    row.lnfk = c.lnFK;
+    row.fa = bs_price<VARIANT, true>(c, BRENT_XA, tab);
+    row.fb = bs_price<VARIANT, true>(c, BRENT_XB, tab);
+    row.pad = 0.0;
+    reinterpret_cast<PointRow *>(g.point)[i] = row;
+}
 
 template <int GT>
 __device__ __forceinline__ void group_sync()
@@ -306,19 +335,23 @@ __device__ __forceinline__ void group_sync()
 // 1/(2n) away from an integer, far more than the float rounding)
 __device__ __forceinline__ int small_div(int j, float inv) { return (int)(((float)j + 0.5f) * inv); }
 
-enum { PH_IDLE = 0, PH_FA = 1, PH_FB = 2, PH_ITER = 3, PH_REJECT = 4 };
-
-template <int VARIANT, bool CHECKS, int GT>
-__global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *__restrict__ ratio, int64_t N,
-                                                      double spot, double *__restrict__ iv_out,
-                                                      int32_t *__restrict__ flags)
+__device__ __forceinline__ bool opposite_sign(double a, double b)
 {
-    constexpr int NG = 256 / GT;
+    return ((__double2hiint(a) ^ __double2hiint(b)) < 0);
+}
+
+enum { PH_IDLE = 0, PH_ITER = 1, PH_DONE = 2 };
+
+template <int VARIANT, bool CHECKS, int GT, int THREADS>
+__global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const double *__restrict__ ratio,
+                                                          int64_t N, double spot, double *__restrict__ iv_out,
+                                                          int32_t *__restrict__ flags)
+{
+    constexpr int NG = THREADS / GT;
     extern __shared__ double dyn[];
     const int nT = g.nT, nK = g.nK, per = nT * nK;
     double *tab = dyn;                                   // ERFCX_LDS
-    double *lnfk = tab + ERFCX_LDS;                      // [per] log(F/K) (variant A)
-    MatRow *mat = reinterpret_cast<MatRow *>(lnfk + per);   // [64]
+    MatRow *mat = reinterpret_cast<MatRow *>(tab + ERFCX_LDS);                // [64]
     double *strike = reinterpret_cast<double *>(mat + AFIV_MAX_MATURITIES);   // [64]
     double *logm = strike + AFIV_MAX_STRIKES;            // [64]
     double *price_all = logm + AFIV_MAX_STRIKES;         // [NG][per]
@@ -328,13 +361,10 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
     double *price = price_all + (size_t)gid * per;
     int *skip_t = skip_all[gid];
     int *ctr = ctr_all[gid];
+    const PointRow *__restrict__ point = reinterpret_cast<const PointRow *>(g.point);
 
     load_erfcx_table(tab);
-    for (int i = tid; i < per; i += 256) {
-        const int t = i / nK, k = i - t * nK;
-        lnfk[i] = log((spot * g.fwd_mult[t]) / (spot * g.Kmult[k]));
-    }
-    for (int t = tid; t < nT; t += 256) {
+    for (int t = tid; t < nT; t += THREADS) {
         MatRow m;
         m.tau = g.tau[t];
         m.sqrt_tau = sqrt(m.tau);
@@ -343,7 +373,7 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
         m.sdq = spot * g.dq_tau[t];
         mat[t] = m;
     }
-    for (int k = tid; k < nK; k += 256) {
+    for (int k = tid; k < nK; k += THREADS) {
         strike[k] = spot * g.Kmult[k];
         logm[k] = g.logm[k];
     }
@@ -352,8 +382,7 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
     const float inv_nT = 1.0f / (float)nT, inv_nK = 1.0f / (float)nK;
     const double nan = __builtin_nan("");
     const double rq = g.r - g.q;
-    const double xa = 0.001, xb = 3.0, xtol = 1e-6, rtol = 4 * 2.220446049250313e-16;
-    const int maxiter = 100;
+    const double xa = BRENT_XA, xb = BRENT_XB, xtol = BRENT_XTOL, rtol = BRENT_RTOL;
 
     for (int64_t s = (int64_t)blockIdx.x * NG + gid; s < N; s += (int64_t)gridDim.x * NG) {
         group_sync<GT>();                                // the previous surface's counters have been read
@@ -379,14 +408,29 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
             group_sync<GT>();                            // ratios are overwritten from here on
         }
 
-        // ---- Brent, one objective evaluation per trip --------------------------------------
+        // ---- Brent: per trip the second half of brentq.c's loop body (choose the step), one
+        //      objective evaluation, the first half (re-bracket, convergence test), and the
+        //      hand-over of converged lanes to new points ----------------------------------------
         int n_nan = 0, n_bad = 0;
         int next = 0;                                    // queue head when the group is one wave
         int phase = PH_IDLE, iter = 0, i_cur = 0;
         bool exhausted = false;
         BsPoint c = {};
-        double x = xa, xpre = 0, xcur = 0, xblk = 0, fpre = 0, fcur = 0, fblk = 0, spre = 0, scur = 0;
+        double res = nan, fr = 0.0;
+        double xpre = xa, xcur = xb, xblk = xa, fpre = 1, fcur = -1, fblk = 1, spre = 0, scur = 0;
+        double delta = 1, sbis = 1;
         for (;;) {
+            // -- finished lanes store; idle lanes take the next point of the queue
+            if (phase == PH_DONE) {
+                if (VARIANT != AFIV_VARIANT_A && (isnan(res) || res <= 0 || res > 3.0)) res = nan;
+                iv_out[s * per + i_cur] = res;
+                if (CHECKS) {
+                    price[i_cur] = fr + c.target;
+                    if (isnan(res)) { n_nan++; n_bad++; }
+                    else if (res <= 0) n_bad++;
+                }
+                phase = PH_IDLE;
+            }
             const bool want = phase == PH_IDLE && !exhausted;
             const unsigned long long wm = __ballot(want);
             if (wm) {
@@ -409,6 +453,7 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
                     } else {
                         const int k = small_div(j, inv_nT), t = j - k * nT;
                         i_cur = t * nK + k;
+                        const PointRow pt = point[i_cur];
                         const MatRow m = mat[t];
                         c.tau = m.tau;
                         c.sqrt_tau = m.sqrt_tau;
@@ -419,7 +464,7 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
                         c.kdr = c.K * c.disc;
                         c.logm = logm[k];
                         c.rq = rq;
-                        c.lnFK = lnfk[i_cur];
+                        c.lnFK = pt.lnfk;
                         const double y = price[i_cur];
                         const double hp = y * spot * c.disc;
                         c.target = hp;
@@ -430,81 +475,82 @@ __global__ __launch_bounds__(256) void surface_kernel(GridView g, const double *
                         } else {
                             ok = !(hp < 1e-10 || isnan(y));
                         }
-                        phase = ok ? PH_FA : PH_REJECT;
-                        x = xa;
+                        // brentq.c up to its loop, then the first half of the loop body for i = 0
+                        const double fa = pt.fa - hp, fb = pt.fb - hp;
+                        res = nan;
+                        fr = 0.0;
+                        phase = PH_DONE;                 // rejected, or decided without iterating
+                        if (ok && !isnan(fa) && !isnan(fb)) {
+                            if (fa == 0) res = xa;
+                            else if (fb == 0) res = xb;
+                            else if (opposite_sign(fa, fb)) {
+                                // the bracket is valid: xblk = xa, fblk = fa, spre = scur = xb - xa,
+                                // swapped so that |fcur| <= |fblk|
+                                const bool sw = fabs(fa) < fabs(fb);
+                                xpre = sw ? xb : xa;  fpre = sw ? fb : fa;
+                                xcur = sw ? xa : xb;  fcur = sw ? fa : fb;
+                                xblk = xpre;          fblk = fpre;
+                                spre = scur = xb - xa;
+                                delta = (xtol + rtol * fabs(xcur)) / 2;
+                                sbis = (xblk - xcur) / 2;
+                                iter = 0;
+                                phase = PH_ITER;         // |sbis| = 1.4995 > delta: never done here
+                            }
+                        }
                     }
                 }
             }
             if (__ballot(phase != PH_IDLE) == 0) break;  // nothing in flight and the queue is empty
 
-            const double f = bs_price<VARIANT, true>(c, x, tab) - c.target;
-
-            bool fin = false;
-            double res = nan, fr = 0.0;
-            if (phase == PH_FA) {
-                fpre = f;
-                fin = isnan(f);
-                phase = PH_FB;
-                x = xb;
-            } else if (phase == PH_REJECT) {
-                fin = true;
-            } else if (phase != PH_IDLE) {
-                bool step = true;
-                fcur = f;
-                if (phase == PH_FB) {
-                    xpre = xa;
-                    xcur = xb;
-                    if (isnan(f)) { fin = true; step = false; }
-                    else if (fpre == 0) { fin = true; res = xa; step = false; }
-                    else if (fcur == 0) { fin = true; res = xb; step = false; }
-                    else if (signbit(fpre) == signbit(fcur)) { fin = true; step = false; }
-                    xblk = 0; fblk = 0; spre = 0; scur = 0;
-                    iter = 0;
-                    phase = PH_ITER;
-                } else {
-                    iter++;
-                    if (isnan(f) || iter == maxiter) { fin = true; step = false; }
-                }
-                if (step) {
-                    // scipy/optimize/Zeros/brentq.c, one pass of its loop body up to the evaluation
-                    if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
-                        xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
-                    }
-                    if (fabs(fblk) < fabs(fcur)) {
-                        xpre = xcur; xcur = xblk; xblk = xpre;
-                        fpre = fcur; fcur = fblk; fblk = fpre;
-                    }
-                    const double delta = (xtol + rtol * fabs(xcur)) / 2;
-                    const double sbis = (xblk - xcur) / 2;
-                    if (fcur == 0 || fabs(sbis) < delta) {
-                        fin = true; res = xcur; fr = fcur;
-                    }
-                    const bool interp = fabs(spre) > delta && fabs(fcur) < fabs(fpre);
-                    const bool sec = xpre == xblk;
-                    // secant: -fcur (xcur - xpre) / (fcur - fpre); otherwise dpre = (fpre - fcur)/(xpre - xcur)
-                    const double q1 = fdivq(sec ? -fcur * (xcur - xpre) : fpre - fcur, sec ? fcur - fpre : xpre - xcur);
-                    const double dblk = fdivq(fblk - fcur, xblk - xcur);
-                    const double q3 = fdivq(-fcur * (fblk * dblk - fpre * q1), dblk * q1 * (fblk - fpre));
-                    const double stry = sec ? q1 : q3;
-                    const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
-                    const bool take = interp && 2 * fabs(stry) < lim;
-                    spre = take ? scur : sbis;
-                    scur = take ? stry : sbis;
-                    xpre = xcur; fpre = fcur;
-                    if (fabs(scur) > delta) xcur += scur;
-                    else xcur += (sbis > 0 ? delta : -delta);
-                    x = xcur;
-                }
+            // -- second half of the loop body: interpolate or bisect
+            {
+                const bool interp = fabs(spre) > delta && fabs(fcur) < fabs(fpre);
+                const bool sec = xpre == xblk;
+                const double a = fpre - fcur, b = xpre - xcur;
+                // secant: -fcur (xcur - xpre) / (fcur - fpre) = -((fcur b) / a); otherwise dpre = a / b
+                const double q = fdivq(sec ? fcur * b : a, sec ? a : b);
+                const double dblk = fdivq(fblk - fcur, xblk - xcur);
+                const double q3 = fdivq(-fcur * (fblk * dblk - fpre * q), dblk * q * (fblk - fpre));
+                const double stry = sec ? -q : q3;
+                const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
+                const bool take = interp && 2 * fabs(stry) < lim;
+                spre = take ? scur : sbis;
+                scur = take ? stry : sbis;
+                xpre = xcur;
+                fpre = fcur;
+                const double sd = sbis > 0 ? delta : -delta;
+                xcur += fabs(scur) > delta ? scur : sd;
             }
-            if (fin) {
-                if (VARIANT != AFIV_VARIANT_A && (isnan(res) || res <= 0 || res > 3.0)) res = nan;
-                iv_out[s * per + i_cur] = res;
-                if (CHECKS) {
-                    price[i_cur] = fr + c.target;
-                    if (isnan(res)) { n_nan++; n_bad++; }
-                    else if (res <= 0) n_bad++;
+
+            const double f = bs_price<VARIANT, true>(c, xcur, tab) - c.target;
+
+            // -- first half of the next pass: re-bracket, order, convergence test
+            if (phase == PH_ITER) {
+                fcur = f;
+                iter++;
+                const bool sgn = fpre != 0 && fcur != 0 && opposite_sign(fpre, fcur);
+                const double dx = xcur - xpre;
+                xblk = sgn ? xpre : xblk;
+                fblk = sgn ? fpre : fblk;
+                spre = sgn ? dx : spre;
+                scur = sgn ? dx : scur;
+                const bool sw = fabs(fblk) < fabs(fcur);
+                const double xc = xcur, fc = fcur;
+                xpre = sw ? xc : xpre;
+                xcur = sw ? xblk : xc;
+                xblk = sw ? xc : xblk;
+                fpre = sw ? fc : fpre;
+                fcur = sw ? fblk : fc;
+                fblk = sw ? fc : fblk;
+                delta = (xtol + rtol * fabs(xcur)) / 2;
+                sbis = (xblk - xcur) / 2;
+                const bool failed = isnan(f) || iter == BRENT_MAXITER;
+                const bool done = fcur == 0 || fabs(sbis) < delta;
+                if (failed || done) {
+                    res = failed ? nan : xcur;
+                    fr = failed ? 0.0 : fcur;
+                    phase = PH_DONE;
                 }
-                phase = PH_IDLE;
             }
         }
 
@@ -658,26 +704,28 @@ int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t 
 namespace {
 size_t surface_lds_bytes(const GridView &g, int groups)
 {
-    return sizeof(double) * ((size_t)ERFCX_LDS + (size_t)g.nT * g.nK + 5 * AFIV_MAX_MATURITIES +
-                             2 * AFIV_MAX_STRIKES + (size_t)groups * g.nT * g.nK);
+    return sizeof(double) * ((size_t)ERFCX_LDS + 5 * AFIV_MAX_MATURITIES + 2 * AFIV_MAX_STRIKES +
+                             (size_t)groups * g.nT * g.nK);
 }
 
-template <int VARIANT, bool CHECKS, int GT>
+template <int VARIANT, bool CHECKS, int GT, int THREADS>
 int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
                           int32_t *flags, hipStream_t s)
 {
-    constexpr int NG = 256 / GT;
+    constexpr int NG = THREADS / GT;
     const size_t lds = surface_lds_bytes(g, NG);
     if (lds > 48 * 1024) {
         // raising the dynamic-LDS limit is a per-function attribute, not an allocation
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
     }
+    const int per = g.nT * g.nK;
+    hipLaunchKernelGGL(point_table_kernel<VARIANT>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, g, spot);
     int64_t blocks = (N + NG - 1) / NG;
     if (blocks > 256 * 24) blocks = 256 * 24;
-    hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS, GT>), dim3((unsigned)blocks), dim3(256), lds, s, g, ratio,
-                       N, spot, iv_out, flags);
+    hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS, GT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), lds,
+                       s, g, ratio, N, spot, iv_out, flags);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -686,9 +734,9 @@ int launch_surface_grouped(const GridView &g, const double *ratio, int64_t N, do
                            int32_t *flags, hipStream_t s)
 {
     // a wave per surface needs surfaces enough to fill the chip and room for two workgroups per CU
-    if (N >= 2048 && surface_lds_bytes(g, 4) <= 76 * 1024)
-        return launch_surface_kernel<VARIANT, CHECKS, 64>(g, ratio, N, spot, iv_out, flags, s);
-    return launch_surface_kernel<VARIANT, CHECKS, 256>(g, ratio, N, spot, iv_out, flags, s);
+    if (N >= 2048 && surface_lds_bytes(g, AFIV_IV_THREADS / 64) <= 76 * 1024)
+        return launch_surface_kernel<VARIANT, CHECKS, 64, AFIV_IV_THREADS>(g, ratio, N, spot, iv_out, flags, s);
+    return launch_surface_kernel<VARIANT, CHECKS, 256, 256>(g, ratio, N, spot, iv_out, flags, s);
 }
 }  // namespace
 

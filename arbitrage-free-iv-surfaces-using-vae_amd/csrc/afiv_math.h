@@ -73,12 +73,12 @@ __device__ __forceinline__ double rcp_f64(double x)
     return __builtin_fma(r, e, r);
 }
 
+// exp(x) for finite x in [-2000, 709]: no clamping and no NaN handling (0 below -745.2).
 template <bool PINNED = true>
-__device__ __forceinline__ double exp_f64(double x)
+__device__ __forceinline__ double exp_core_f64(double x)
 {
-    const double xc = fmin(fmax(x, -1000.0), 1000.0);          // keeps k inside int range; NaN -> finite garbage is avoided below
-    const double k = __builtin_rint(xc * AFIV_LOG2E);
-    double r = __builtin_fma(k, -AFIV_LN2_HI, xc);
+    const double k = __builtin_rint(x * AFIV_LOG2E);
+    double r = __builtin_fma(k, -AFIV_LN2_HI, x);
     r = __builtin_fma(k, -AFIV_LN2_LO, r);
     const coef_ptr c_exp = (PINNED ? coeffs(r) : coeffs_hoistable()) + OFF_EXP;
     double p = c_exp[13];
@@ -95,8 +95,15 @@ __device__ __forceinline__ double exp_f64(double x)
     p = fma_sc(p, r, c_exp[2]);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    const double y = __builtin_ldexp(p, (int)k);                // v_ldexp_f64: exact scaling, graceful under/overflow
-    return x != x ? x : y;                                      // NaN in, NaN out
+    return __builtin_ldexp(p, (int)k);                          // v_ldexp_f64: exact scaling, graceful underflow
+}
+
+template <bool PINNED = true>
+__device__ __forceinline__ double exp_f64(double x)
+{
+    // the clamp keeps the exponent inside int range; NaN in, NaN out
+    const double y = exp_core_f64<PINNED>(fmin(fmax(x, -1000.0), 1000.0));
+    return x != x ? x : y;
 }
 
 // sin and cos of the same argument.
