@@ -1,0 +1,250 @@
+"""GPU parity on the five benchmark configurations (BASELINE.json `configs`), through the C ABI.
+
+  1  repo default: 100 samples decoded from one conditioning row, 8 x 21 lattice, variant A
+  2  all 500 historical dates x 100 samples (50 000 surfaces): oracle on a sample, and at full
+     size the size-independent properties (fused = separate passes bit for bit, Black-Scholes
+     round trip price -> vol -> price, flags recomputed from the outputs)
+  3  the 20 x 50 lattice at benchmark batch size: the same properties plus oracle on a sample
+  4  calibration Stage-1 loss matrix, candidates x days
+  5  stress grid: |rho| -> 1, sigma_v from 1e-5 to 5, maturities of 7..60 days, Feller violations
+
+Tolerances are those of test_gpu_parity.py (its module docstring states them).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_gpu_parity import (LOGM_GRID, Q, R, SPOT, T_GRID, assert_iv_close, assert_params_close, dev,
+                             price_tol, sample_params)
+
+pytestmark = pytest.mark.gpu
+
+
+def load_decoder(afiv, golden_dir):
+    d = np.load(f"{golden_dir}/decoder.npz")
+    sd = {k: d[k] for k in d.files if k.startswith("decoder.")}
+    return afiv.Decoder(sd, d["param_mean"], d["param_std"]), sd, d
+
+
+def bs_forward_price(iv, logm, tau, spot, r, q):
+    """Variant-A Black-Scholes value on the lattice, float64 torch on the GPU
+    (generate_iv_surface_by_date.py:308-311)."""
+    T = torch.as_tensor(tau, dtype=torch.float64, device=iv.device)[None, :, None]
+    lm = torch.as_tensor(logm, dtype=torch.float64, device=iv.device)[None, None, :]
+    F = spot * torch.exp((r - q) * T)
+    K = spot * torch.exp(lm)
+    st = torch.sqrt(T)
+    d1 = (torch.log(F / K) + 0.5 * iv * iv * T) / (iv * st)
+    d2 = d1 - iv * st
+    nd = torch.special.ndtr
+    price = torch.exp(-r * T) * (F * nd(d1) - K * nd(d2))
+    vega = torch.exp(-r * T) * F * torch.exp(-0.5 * d1 * d1) / np.sqrt(2 * np.pi) * st
+    return price, vega
+
+
+def assert_round_trip(iv, ratio, logm, tau, spot, r, q):
+    """price -> implied vol -> price: wherever a vol was found, Black-Scholes at that vol returns
+    the Heston price to within Brent's tolerance (|d vol| <= 1e-6) times vega."""
+    T = torch.as_tensor(tau, dtype=torch.float64, device=iv.device)[None, :, None]
+    target = ratio * spot * torch.exp(-r * T)
+    price, vega = bs_forward_price(iv, logm, tau, spot, r, q)
+    ok = ~torch.isnan(iv)
+    err = (price - target).abs()[ok]
+    bound = (1.01e-6 * vega + 1e-9 * spot)[ok]
+    assert bool((err <= bound).all()), f"round trip off by {float((err - bound).max()):.3g}"
+
+
+def recomputed_flags(iv, ratio, logm, tau, spot, r, q):
+    """Flags of the fused kernel recomputed with torch from its own outputs (variant A form)."""
+    price, _ = bs_forward_price(iv, logm, tau, spot, r, q)
+    bad = (torch.isnan(iv) | (iv <= 0)).flatten(1).any(1)
+    stat = (price[:, :, :-1] < price[:, :, 1:] - 1e-6).flatten(1).sum(1)
+    cal = (price[:, :-1, :] > price[:, 1:, :] + 1e-6).flatten(1).sum(1)
+    skip = (torch.isnan(ratio) | (ratio < 0)).any(2, keepdim=True)
+    b = ratio[:, :, :-2] - 2 * ratio[:, :, 1:-1] + ratio[:, :, 2:]
+    fly = ((b < 0) & ~skip).flatten(1).sum(1)
+    return bad, stat, cal, fly
+
+
+def test_config1_repo_default_100_samples(afiv, golden_dir):
+    dec, sd, d = load_decoder(afiv, golden_dir)
+    g = torch.Generator().manual_seed(20251110)
+    z = torch.randn(100, 4, generator=g)
+    c = torch.as_tensor(d["cond_rows"][-1:], dtype=torch.float32)       # 2025-06-27, z-scored
+    out = dec.decode(z.cuda(), c.cuda())
+    ref_params = oracle.decode_params(z.numpy(), np.repeat(c.numpy(), 100, 0), sd, d["param_mean"], d["param_std"])
+    assert_params_close(out["params32"].cpu().numpy(), ref_params)
+    grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
+    p64 = out["params64"]
+    iv, flags, ratio = grid.surface(p64, SPOT, "A")
+    p = p64.cpu().numpy()
+    ref_ratio = oracle.price_ratio_grid(p, LOGM_GRID, T_GRID, R, Q)
+    assert np.all(np.abs(ratio.cpu().numpy() - ref_ratio) <= price_tol(ref_ratio, p))
+    iv_o = oracle.implied_vol_grid(ratio.cpu().numpy(), LOGM_GRID, T_GRID, SPOT, R, Q, "A")
+    assert_iv_close(iv.cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q)
+    flags_o = oracle.arb_check(iv.cpu().numpy(), ratio.cpu().numpy(), LOGM_GRID, T_GRID, SPOT, R, Q, "A")
+    assert np.array_equal(flags.cpu().numpy(), flags_o)
+    # the reference's success rule (generate_iv_surface_by_date.py:321) from the status word
+    nan_frac = np.isnan(iv.cpu().numpy()).reshape(100, -1).mean(1)
+    assert np.array_equal((flags.cpu().numpy()[:, 3] & 8) != 0, nan_frac < 0.1)
+
+
+def test_config2_all_dates_100_samples_each(afiv, golden_dir):
+    dec, sd, d = load_decoder(afiv, golden_dir)
+    rows = d["cond_rows"]
+    assert rows.shape == (500, 8)
+    zs = []
+    for i in range(500):
+        zs.append(torch.randn(100, 4, generator=torch.Generator().manual_seed(1000 + i)))
+    z = torch.cat(zs).cuda()
+    c = torch.as_tensor(rows, dtype=torch.float32).repeat_interleave(100, 0).cuda()
+    params = dec.decode(z, c)["params64"]
+    assert params.shape == (50000, 5)
+    grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
+    iv, flags, ratio = grid.surface(params, SPOT, "A")
+    # full size: fused launch = separate launches, round trip, flags from the outputs
+    iv_s = grid.implied_vol(ratio, SPOT, "A")
+    fl_s = grid.arb_check(iv_s, ratio, SPOT, "A")
+    assert torch.equal(torch.nan_to_num(iv, nan=-1.0), torch.nan_to_num(iv_s, nan=-1.0))
+    assert torch.equal(flags, fl_s)
+    assert_round_trip(iv, ratio, LOGM_GRID, T_GRID, SPOT, R, Q)
+    # oracle on a sample of dates and draws
+    pick = np.random.default_rng(2).choice(50000, 48, replace=False)
+    p = params[pick].cpu().numpy()
+    ref_ratio = oracle.price_ratio_grid(p, LOGM_GRID, T_GRID, R, Q)
+    got = ratio[pick].cpu().numpy()
+    assert np.all(np.abs(got - ref_ratio) <= price_tol(ref_ratio, p))
+    iv_o = oracle.implied_vol_grid(got, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
+    assert_iv_close(iv[pick].cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q)
+    flags_o = oracle.arb_check(iv[pick].cpu().numpy(), got, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
+    assert np.array_equal(flags[pick].cpu().numpy(), flags_o)
+
+
+def test_config3_benchmark_lattice_at_batch_size(afiv):
+    logm = np.linspace(-0.2, 0.2, 50)
+    tau = np.round(np.linspace(30, 730, 20)) / 365.0
+    grid = afiv.Grid(logm, tau, R, Q)
+    n = 16384
+    params = dev(sample_params(n, 3))
+    ratio = grid.price(params)
+    iv, flags = grid.implied_vol_checked(ratio, SPOT, "A")
+    # determinism: a second run is bit-identical
+    ratio2 = grid.price(params)
+    iv2, flags2 = grid.implied_vol_checked(ratio2, SPOT, "A")
+    assert torch.equal(torch.nan_to_num(ratio, nan=-1.0), torch.nan_to_num(ratio2, nan=-1.0))
+    assert torch.equal(torch.nan_to_num(iv, nan=-1.0), torch.nan_to_num(iv2, nan=-1.0))
+    assert torch.equal(flags, flags2)
+    # a surface's result does not depend on the batch around it (wave-per-surface mode vs the
+    # workgroup-per-surface mode taken for small batches)
+    sub = slice(100, 140)
+    iv_small, flags_small = grid.implied_vol_checked(ratio[sub].contiguous(), SPOT, "A")
+    assert torch.equal(torch.nan_to_num(iv[sub], nan=-1.0), torch.nan_to_num(iv_small, nan=-1.0))
+    assert torch.equal(flags[sub], flags_small)
+    assert torch.equal(grid.price(params[sub].contiguous()), ratio[sub])
+    assert_round_trip(iv, ratio, logm, tau, SPOT, R, Q)
+    bad, stat, cal, fly = recomputed_flags(iv, ratio, logm, tau, SPOT, R, Q)
+    f = flags.cpu()
+    assert torch.equal((f[:, 3] & 4) == 0, bad.cpu())
+    assert torch.equal(f[:, 2].long(), fly.cpu())
+    # static / calendar counts sit on a 1e-6 threshold of 21000-scale prices: torch's normal CDF
+    # differs from the kernel's by an ulp, so demand equality only where no difference lies
+    # within 1e-9 of the threshold; the oracle comparison below is exact
+    valid = ~bad.cpu()
+    agree = (f[valid, 0].long() == stat.cpu()[valid]) & (f[valid, 1].long() == cal.cpu()[valid])
+    assert agree.float().mean() > 0.999
+    pick = np.random.default_rng(3).choice(n, 12, replace=False)
+    p = params[pick].cpu().numpy()
+    got = ratio[pick].cpu().numpy()
+    ref_ratio = oracle.price_ratio_grid(p, logm, tau, R, Q)
+    assert np.all(np.abs(got - ref_ratio) <= price_tol(ref_ratio, p))
+    iv_o = oracle.implied_vol_grid(got, logm, tau, SPOT, R, Q, "A")
+    assert_iv_close(iv[pick].cpu().numpy(), iv_o, logm, tau, SPOT, R, Q)
+    flags_o = oracle.arb_check(iv[pick].cpu().numpy(), got, logm, tau, SPOT, R, Q, "A")
+    assert np.array_equal(flags[pick].cpu().numpy(), flags_o)
+
+
+def market_lattice(iv_surfaces, t_grid, logm_grid, r, q):
+    """Market price ratios on the lattice, NaN where the reference drops the point
+    (run_single_heston_calibration.py:177-208: invalid vols, and maturities with < 3 points)."""
+    out = np.full(iv_surfaces.shape, np.nan)
+    for d in range(iv_surfaces.shape[0]):
+        for m in range(len(t_grid)):
+            row = iv_surfaces[d, m]
+            mask = ~np.isnan(row) & (row > 0) & (row < 2.0)
+            if mask.sum() < 3:
+                continue
+            out[d, m, mask] = oracle.market_price_ratio(row[mask], logm_grid[mask], t_grid[m], r, q)
+    return out
+
+
+def test_config4_stage1_loss_matrix(afiv, golden_dir):
+    pin = np.load(f"{golden_dir}/calibration_pin.npz")
+    t_grid, logm_grid = pin["T_grid"], pin["logm_grid"]
+    r, q = float(pin["r"]), float(pin["q"])
+    days = pin["iv_surfaces"]                                   # all 500 days
+    market = market_lattice(days, t_grid, logm_grid, r, q)
+    cand = sample_params(256, 4)
+    cand[:6] = pin["params"][:6]                                # some calibrated sets: small losses
+    grid = afiv.Grid(logm_grid, t_grid, r, q)
+    model = grid.price(dev(cand))
+    loss = grid.stage1_objective(model, dev(cand), dev(market), float(pin["drift_weight"])).cpu().numpy()
+    assert loss.shape == (256, 500)
+    model_h = model.cpu().numpy()
+    rng = np.random.default_rng(4)
+    checked = 0
+    for c in list(range(6)) + list(rng.choice(256, 10, replace=False)):
+        for d in rng.choice(500, 12, replace=False):
+            mask = ~np.isnan(market[d])
+            ref = oracle.stage1_objective(cand[c], days[d], t_grid, logm_grid, r, q, float(pin["drift_weight"]),
+                                          model_pr=model_h[c][mask])
+            assert abs(loss[c, d] - ref) <= 1e-12 * max(1.0, abs(ref)), (c, d, loss[c, d], ref)
+            checked += 1
+    assert checked > 150
+    # and with the oracle's own prices for the calibrated sets (end to end, price tolerance)
+    for c in range(3):
+        for d in (0, 250, 499):
+            ref = oracle.stage1_objective(cand[c], days[d], t_grid, logm_grid, r, q, float(pin["drift_weight"]))
+            if ref < 1e10 and loss[c, d] < 1e10:
+                assert abs(loss[c, d] - ref) <= 1e-7
+    # the Feller term alone separates violating candidates
+    viol = cand[:, 2] ** 2 > 2 * cand[:, 0] * cand[:, 1]
+    assert viol.any() and (~viol).any()
+
+
+STRESS_RHO = (-0.999, -0.99, -0.95, 0.95, 0.999)
+STRESS_SIGMA = (1e-5, 1e-4, 1e-3, 1.0, 3.0, 5.0)
+STRESS_KAPPA = (0.01, 2.0, 20.0)
+STRESS_LEVEL = (0.001, 0.04, 0.25)
+
+
+def test_config5_stress_grid(afiv):
+    sets = np.array([[k, lv, s, rho, lv] for rho in STRESS_RHO for s in STRESS_SIGMA for k in STRESS_KAPPA
+                     for lv in STRESS_LEVEL])
+    assert sets.shape == (270, 5)
+    tau = np.array([7, 14, 30, 60]) / 365.0
+    grid = afiv.Grid(LOGM_GRID, tau, R, Q)
+    ratio = grid.price(dev(sets)).cpu().numpy()
+    ref = oracle.price_ratio_grid(sets, LOGM_GRID, tau, R, Q)
+    assert np.array_equal(np.isnan(ratio), np.isnan(ref)), "NaN masks of the prices differ"
+    ok = ~np.isnan(ref)
+    excess = np.where(ok, np.abs(ratio - ref) / price_tol(ref, sets), 0.0)
+    # per-band report (visible with -s) and the bound itself
+    for s in STRESS_SIGMA:
+        band = sets[:, 2] == s
+        print(f"sigma_v={s:g}: max |d|={np.nanmax(np.abs(ratio - ref)[band]):.3e} "
+              f"max excess={excess[band].max():.3f} NaN={int(np.isnan(ref[band]).sum())}")
+    assert excess.max() <= 1.0
+    wide = sets[:, 2] >= 1.0                                     # conditioning term negligible
+    assert np.all(np.abs(ratio - ref)[wide][ok[wide]] <= price_tol(ref[wide])[ok[wide]])
+    feller_violating = sets[:, 2] ** 2 > 2 * sets[:, 0] * sets[:, 1]
+    assert feller_violating.sum() > 50
+    # solver robustness on the same prices, both variants: guard / NaN agreement and vols
+    for variant in ("A", "B"):
+        iv = grid.implied_vol(dev(ratio), SPOT, variant).cpu().numpy()
+        iv_o = oracle.implied_vol_grid(ratio, LOGM_GRID, tau, SPOT, R, Q, variant)
+        print(f"variant {variant}: NaN on GPU {int(np.isnan(iv).sum())}, oracle {int(np.isnan(iv_o).sum())}, "
+              f"mask mismatches {int((np.isnan(iv) != np.isnan(iv_o)).sum())}")
+        assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, max_ill_mismatch=0.01)
+    flags = grid.arb_check(dev(iv_o), dev(ratio), SPOT, "B").cpu().numpy()
+    assert np.array_equal(flags, oracle.arb_check(iv_o, ratio, LOGM_GRID, tau, SPOT, R, Q, "B"))
