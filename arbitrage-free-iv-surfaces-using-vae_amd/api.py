@@ -202,6 +202,33 @@ class Grid:
         return out
 
 
+MAX_ENSEMBLE = 16384
+
+
+def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torch.Tensor:
+    """nan-aware mean, median, 5th and 95th percentile over the leading (sample) axis of a stack
+    of surfaces [N, ...] -> [4, ...] (generate_iv_surface_by_date.py:474-478; NumPy's default
+    percentile method).  ``select`` is an optional [N] bool / uint8 tensor of the surfaces to
+    include."""
+    v = iv.contiguous()
+    if v.dtype != torch.float64 or not v.is_cuda or v.dim() < 2:
+        raise TypeError("iv must be a CUDA float64 tensor [N, ...]")
+    n = v.shape[0]
+    points = v[0].numel()
+    if n < 1 or n > MAX_ENSEMBLE or points < 1:
+        raise ValueError(f"ensemble_stats takes 1..{MAX_ENSEMBLE} surfaces per call, got {n}")
+    sel = None
+    if select is not None:
+        sel = select.to(device=v.device, dtype=torch.uint8).contiguous()
+        if sel.shape != (n,):
+            raise ValueError(f"select must be [{n}], got {tuple(sel.shape)}")
+    out = torch.empty((4,) + tuple(v.shape[1:]), dtype=torch.float64, device=v.device)
+    with torch.cuda.device(v.device):
+        rc = _lib.lib().afiv_ensemble_stats(_ptr(v), _ptr(sel), n, points, _ptr(out), _stream())
+    _lib.check(rc, "afiv_ensemble_stats")
+    return out
+
+
 MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5}
 
 

@@ -299,6 +299,14 @@ int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const d
                               as_stream(stream));
 }
 
+int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int64_t points,
+                        double *stats_out, void *stream)
+{
+    if (!iv || !stats_out) return AFIV_E_NULL;
+    if (N < 1 || N > AFIV_MAX_ENSEMBLE || points < 1 || points > (1 << 24)) return AFIV_E_SHAPE;
+    return afiv_launch_ensemble(iv, select, N, (int)points, stats_out, as_stream(stream));
+}
+
 int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
                     void *stream)
 {

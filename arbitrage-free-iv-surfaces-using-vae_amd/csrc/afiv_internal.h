@@ -73,3 +73,5 @@ int afiv_launch_debug_math(int op, const double *x, const double *y, int64_t n, 
 int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t s);
 int afiv_launch_surface_iv(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
                            double *iv_out, int32_t *flags, hipStream_t s);
+int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
+                         hipStream_t s);

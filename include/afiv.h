@@ -15,6 +15,10 @@
  *     data (NaN implied vols, flag words), never errors, as in the reference's try/except -> NaN
  *     (generate_iv_surface_by_date.py:316-318).
  *   - All arrays are dense, row-major, in the shapes written next to each argument.
+ *   - Concurrency: calls on different grid / decoder objects are independent.  The calls that
+ *     invert vols (afiv_implied_vol, afiv_implied_vol_checked, afiv_surface) rewrite a small
+ *     per-call table held inside the grid object (and afiv_surface with ratio_out == NULL the
+ *     grid's workspace): issue them on one stream per grid object, or create one grid per stream.
  */
 #ifndef AFIV_H
 #define AFIV_H
@@ -45,6 +49,7 @@ enum {
 /* Limits of this build. */
 #define AFIV_MAX_STRIKES 64      /* strikes per grid */
 #define AFIV_MAX_MATURITIES 64   /* maturities per grid */
+#define AFIV_MAX_ENSEMBLE 16384  /* surfaces per afiv_ensemble_stats call (one LDS-resident column) */
 
 typedef struct afiv_grid afiv_grid;
 typedef struct afiv_decoder afiv_decoder;
@@ -152,6 +157,17 @@ int afiv_arbitrage_penalty(const afiv_grid *g, const double *params, int64_t B, 
 int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const double *params,
                           int64_t C, const double *market_ratio, int64_t D, double drift_weight,
                           double *loss_out, void *stream);
+
+/* ---- ensemble statistics: replaces generate_iv_surface_by_date.py:474-478, i.e.
+ * np.nanmean, np.nanmedian, np.nanpercentile(5) and np.nanpercentile(95) over axis 0 of the
+ * stacked valid surfaces (NumPy's default "linear" percentile method, bit for bit).
+ * iv: device [N,points] with points = nT*nK; select: NULL (use every surface) or device [N]
+ * bytes, nonzero = use (the reference keeps the surfaces whose success flag is set, :466-467);
+ * stats_out: device [4,points] = mean, median, 5th, 95th percentile; a grid point without any
+ * non-NaN value gives NaN.  1 <= N <= AFIV_MAX_ENSEMBLE, points >= 1.  Needs no grid object;
+ * runs on the current device. */
+int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int64_t points,
+                        double *stats_out, void *stream);
 
 /* ---- diagnostics: the kernels' own FP64 elementary functions, element-wise, so that unit tests
  * can check them against high-precision references.  No counterpart in the reference (which

@@ -334,3 +334,39 @@ def test_wrong_dtype_and_shape_are_rejected(afiv, grid821):
         grid821.implied_vol(torch.zeros((2, 8, 20), dtype=torch.float64, device="cuda"), SPOT)
     with pytest.raises(RuntimeError):
         afiv.Grid(np.zeros(65), T_GRID)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 257, 3000])
+def test_ensemble_statistics_equal_numpy_bit_for_bit(afiv, n):
+    """generate_iv_surface_by_date.py:474-478 against NumPy itself (oracle.ensemble_stats)."""
+    rng = np.random.default_rng(n)
+    s = 0.2 + 0.05 * rng.standard_normal((n, 8, 21))
+    s[rng.random(s.shape) < 0.15] = np.nan                      # the NaN wedge of short maturities
+    s[:, 0, :3] = np.nan                                         # grid points without any value
+    if n > 2:
+        s[:, 1, 0] = np.nan
+        s[0, 1, 0] = 0.3                                         # a single value
+        s[:, 2, 5] = 0.25                                        # all equal
+    got = afiv.ensemble_stats(dev(s)).cpu().numpy()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = np.stack(oracle.ensemble_stats(s))
+    assert got.shape == ref.shape == (4, 8, 21)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(ref, nan=-1.0)), \
+        f"max difference {np.nanmax(np.abs(got - ref)):.3g}"
+
+
+def test_ensemble_statistics_select_and_limits(afiv):
+    rng = np.random.default_rng(5)
+    s = 0.2 + 0.05 * rng.standard_normal((300, 4, 6))
+    keep = rng.random(300) < 0.6
+    got = afiv.ensemble_stats(dev(s), torch.as_tensor(keep).cuda()).cpu().numpy()
+    ref = np.stack(oracle.ensemble_stats(s[keep]))
+    assert np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        afiv.ensemble_stats(torch.zeros((afiv.MAX_ENSEMBLE + 1, 2, 2), dtype=torch.float64, device="cuda"))
+    big = 0.2 + 0.01 * rng.standard_normal((afiv.MAX_ENSEMBLE, 2, 3))
+    got = afiv.ensemble_stats(dev(big)).cpu().numpy()
+    assert np.array_equal(got, np.stack(oracle.ensemble_stats(big)))
