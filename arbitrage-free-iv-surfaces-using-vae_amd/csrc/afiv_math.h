@@ -73,7 +73,9 @@ __device__ __forceinline__ double rcp_f64(double x)
     return __builtin_fma(r, e, r);
 }
 
-// exp(x) for finite x in [-2000, 709]: no clamping and no NaN handling (0 below -745.2).
+// exp(x) without clamping or special-value selects: exact limits for every finite x (the
+// float-to-int conversion saturates and v_ldexp_f64 then under/overflows to 0 / +inf), NaN for a
+// NaN argument (it propagates through the reduction), but NaN -- not 0 or +inf -- for x = -+inf.
 template <bool PINNED = true>
 __device__ __forceinline__ double exp_core_f64(double x)
 {

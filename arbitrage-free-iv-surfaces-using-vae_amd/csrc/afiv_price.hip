@@ -143,7 +143,7 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
 __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, double phi, double wp,
                                            double T, double ddt, double disc)
 {
-    const double er = afivm::exp_f64(-s.d.r * T);
+    const double er = afivm::exp_core_f64(-s.d.r * T);
     double sn, cs;
     afivm::sincos_f64(s.d.i * T, &sn, &cs);
     const Cx ex = {er * cs, -er * sn};               // exp(-d T)
@@ -166,7 +166,7 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gl.i / m.sigma2);
     }
     const double alpha = A.i + phi * ddt;
-    const double E = wp * afivm::exp_f64(A.r) * disc;
+    const double E = wp * afivm::exp_core_f64(A.r) * disc;
     double sa, ca;
     afivm::sincos_f64(alpha, &sa, &ca);
     return make_double2(E * sa, E * ca);
