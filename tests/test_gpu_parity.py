@@ -370,3 +370,19 @@ def test_ensemble_statistics_select_and_limits(afiv):
     big = 0.2 + 0.01 * rng.standard_normal((afiv.MAX_ENSEMBLE, 2, 3))
     got = afiv.ensemble_stats(dev(big)).cpu().numpy()
     assert np.array_equal(got, np.stack(oracle.ensemble_stats(big)))
+
+
+def test_price_against_50_digit_quadrature_at_small_vol_of_vol(afiv, golden_dir):
+    """Where the double-precision oracle (and any evaluation of the reference formula as written)
+    carries eps / sigma_v^2 of noise, the kernel's cancellation-free forms stay within the PLAIN
+    1e-8 rule -- in fact within 1e-14 -- of the exactly evaluated quadrature
+    (tests/golden/make_exact_prices.py)."""
+    g = np.load(f"{golden_dir}/exact_prices.npz")
+    grid = afiv.Grid(g["logm"], g["tau"], float(g["r"]), float(g["q"]))
+    got = grid.price(dev(g["params"])).cpu().numpy()
+    ref = g["ratio"]
+    assert np.all(np.abs(got - ref) <= price_tol(ref))          # no conditioning term
+    assert np.abs(got - ref).max() <= 1e-14
+    orc = oracle.price_ratio_grid(g["params"], g["logm"], g["tau"], float(g["r"]), float(g["q"]))
+    assert np.all(np.abs(orc - ref) <= price_tol(ref, g["params"]))
+    assert np.abs(orc - ref).max() > 100 * np.abs(got - ref).max()

@@ -173,3 +173,19 @@ def test_ensemble_statistics_ignore_nans():
     assert np.allclose(mean, [[0.2, 0.3]])
     assert np.allclose(med, [[0.2, 0.3]])
     assert np.allclose(p5, [[0.11, 0.21]])
+
+
+def test_oracle_noise_against_50_digit_quadrature(golden_dir):
+    """The reference formula divides two cancelling quantities by sigma_v^2; evaluated in doubles
+    as written (which is what the oracle restates) it is eps / sigma_v^2 away from the exactly
+    evaluated quadrature.  This is the conditioning term of the GPU tests' price tolerance."""
+    g = np.load(f"{golden_dir}/exact_prices.npz")
+    ref = g["ratio"]
+    got = oracle.price_ratio_grid(g["params"], g["logm"], g["tau"], float(g["r"]), float(g["q"]))
+    sig = g["params"][:, 2][:, None, None]
+    eps = np.finfo(float).eps
+    assert np.all(np.abs(got - ref) <= 1e-8 * np.maximum(np.abs(ref), 1e-4) + 16 * eps / sig ** 2)
+    small = g["params"][:, 2] <= 1e-3
+    assert np.abs(got - ref)[small].max() > 1e-12           # the plain bound alone would not hold
+    wide = g["params"][:, 2] >= 0.03
+    assert np.abs(got - ref)[wide].max() < 1e-12
