@@ -133,12 +133,15 @@ __device__ __forceinline__ void sincos_f64(double x, double *s_out, double *c_ou
     pc = fma_sc(pc, z, c_cos[1]);
     pc = fma_sc(pc, z, c_cos[0]);
     const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    // quadrant: x = r + q pi/2
+    // quadrant: x = r + q pi/2.  Odd q swaps the two; the signs are bit 1 of q (sin) and of
+    // q + 1 (cos) moved into the sign bit.
     const bool swap = q & 1;
-    double s = swap ? cs : sn;
-    double c = swap ? sn : cs;
-    s = (q & 2) ? -s : s;
-    c = ((q + 1) & 2) ? -c : c;
+    const double s0 = swap ? cs : sn;
+    const double c0 = swap ? sn : cs;
+    const unsigned qs = (unsigned)q << 30;
+    const double s = __hiloint2double(__double2hiint(s0) ^ (int)(qs & 0x80000000u), __double2loint(s0));
+    const double c = __hiloint2double(__double2hiint(c0) ^ (int)((qs + 0x40000000u) & 0x80000000u),
+                                      __double2loint(c0));
     *s_out = s;
     *c_out = c;
 }
