@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--surfaces-per-gpu", type=int, default=SURFACES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo rehearses the multi-rank path on a box with fewer GPUs than ranks "
+                         "(ranks share devices, the flag words are gathered through host memory)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,11 +105,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
                          "python -m torch.distributed.run --nproc-per-node N)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     afiv = afiv_bootstrap.load()
     logm, tau = grids()
@@ -131,7 +139,13 @@ def main():
         if events:
             events[2].record()
         if world > 1:
-            dist.all_gather_into_tensor(flags_all, flags_local)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(flags_all, flags_local)
+            else:
+                host = flags_local.cpu()
+                gathered = torch.empty((world * n_local, 4), dtype=torch.int32)
+                dist.all_gather_into_tensor(gathered, host)
+                flags_all.copy_(gathered)
         return flags_local
 
     for _ in range(args.warmup):
@@ -149,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
