@@ -6,7 +6,7 @@
 //
 //   implied vol : generate_iv_surface_by_date.py:296-318 (variant A) and
 //                 generate_regime_surfaces.py:138-177 (variant B); the root finder follows
-//                 scipy.optimize.brentq step for step (one lane per grid point), because
+//                 scipy.optimize.brentq step for step (one grid point per lane at a time), because
 //                 variant B's objective is not monotone and only the same iteration path
 //                 lands on the same root.
 //   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
@@ -103,58 +103,6 @@ __device__ __forceinline__ double bs_price(const BsPoint &c, double iv, const do
         const double d2 = d1 - iv * c.sqrt_tau;
         return c.sdq * ndtr_dev<!FAST>(d1, tab) - c.kdr * ndtr_dev<!FAST>(d2, tab);
     }
-}
-
-// scipy/optimize/Zeros/brentq.c with the Python wrapper's NaN check; NaN on any failure.
-template <int VARIANT>
-__device__ double brentq_dev(const BsPoint &c, const double *__restrict__ tab, double xa, double xb,
-                             double xtol, double rtol, int maxiter, double *f_at_root)
-{
-    *f_at_root = 0.0;
-    double xpre = xa, xcur = xb, xblk = 0.0, fpre, fcur, fblk = 0.0, spre = 0.0, scur = 0.0;
-    double sbis, delta, stry, dpre, dblk;
-    const double nan = __builtin_nan("");
-    fpre = bs_price<VARIANT>(c, xpre, tab) - c.target;
-    if (isnan(fpre)) return nan;
-    fcur = bs_price<VARIANT>(c, xcur, tab) - c.target;
-    if (isnan(fcur)) return nan;
-    if (fpre == 0) return xpre;
-    if (fcur == 0) return xcur;
-    if (signbit(fpre) == signbit(fcur)) return nan;
-    // value of the objective at the returned abscissa: lets a caller re-price for free
-    // (price = objective + target, exact by Sterbenz' lemma at a root)
-    for (int i = 0; i < maxiter; ++i) {
-        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
-            xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
-        }
-        if (fabs(fblk) < fabs(fcur)) {
-            xpre = xcur; xcur = xblk; xblk = xpre;
-            fpre = fcur; fcur = fblk; fblk = fpre;
-        }
-        delta = (xtol + rtol * fabs(xcur)) / 2;
-        sbis = (xblk - xcur) / 2;
-        if (fcur == 0 || fabs(sbis) < delta) { *f_at_root = fcur; return xcur; }
-        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
-            if (xpre == xblk) {
-                stry = -fcur * (xcur - xpre) / (fcur - fpre);
-            } else {
-                dpre = (fpre - fcur) / (xpre - xcur);
-                dblk = (fblk - fcur) / (xblk - xcur);
-                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
-            }
-            const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
-            if (2 * fabs(stry) < lim) { spre = scur; scur = stry; }
-            else { spre = sbis; scur = sbis; }
-        } else {
-            spre = sbis; scur = sbis;
-        }
-        xpre = xcur; fpre = fcur;
-        if (fabs(scur) > delta) xcur += scur;
-        else xcur += (sbis > 0 ? delta : -delta);
-        fcur = bs_price<VARIANT>(c, xcur, tab) - c.target;
-        if (isnan(fcur)) return nan;
-    }
-    return nan;   // not converged: the reference's brentq raises -> NaN
 }
 
 __device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, double spot)
