@@ -52,6 +52,8 @@ SIGNATURES = {
     "afiv_arbitrage_penalty": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "afiv_stage1_objective": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_double,
                                       c_void_p, c_void_p]),
+    "afiv_density_wasserstein": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                                         c_void_p]),
     "afiv_ensemble_stats": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "afiv_debug_math": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
 }

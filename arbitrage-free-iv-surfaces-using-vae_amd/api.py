@@ -202,6 +202,34 @@ class Grid:
         return out
 
 
+    def density_wasserstein(self, model_ratio: torch.Tensor, market_ratio: torch.Tensor) -> torch.Tensor:
+        """Per-maturity density-Wasserstein distances [C,D,nT] on this (fine) grid
+        (run_single_heston_calibration.py:100-151): +inf where the reference returns inf, NaN for
+        maturities marked absent by a NaN market row."""
+        mr = self._lattice(model_ratio, "model_ratio")
+        mk = self._lattice(market_ratio, "market_ratio")
+        c, d = mr.shape[0], mk.shape[0]
+        out = torch.empty((c, d, self.nT), dtype=torch.float64, device=self.device)
+        scratch = torch.empty(((c + d) * self.nT * (self.nK + 1),), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().afiv_density_wasserstein(self._h, _ptr(mr), c, _ptr(mk), d, _ptr(scratch),
+                                                     _ptr(out), _stream())
+        _lib.check(rc, "afiv_density_wasserstein")
+        return out
+
+    def stage2_objective(self, stage1_loss: torch.Tensor, dist: torch.Tensor,
+                         wasserstein_weight: float = 1.0) -> torch.Tensor:
+        """objective_stage2 (:342-406) from the Stage-1 loss matrix [C,D] (on the market grid) and
+        the distances of ``density_wasserstein`` [C,D,nT]: base + weight * mean(finite distances),
+        1e10 where the base already is."""
+        finite = torch.isfinite(dist)
+        cnt = finite.sum(-1)
+        avg = torch.where(cnt > 0, torch.where(finite, dist, torch.zeros_like(dist)).sum(-1) / cnt.clamp(min=1),
+                          torch.zeros_like(stage1_loss))
+        total = stage1_loss + wasserstein_weight * avg
+        return torch.where(stage1_loss >= 1e10, torch.full_like(total, 1e10), total)
+
+
 MAX_ENSEMBLE = 16384
 
 

@@ -299,6 +299,19 @@ int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const d
                               as_stream(stream));
 }
 
+int afiv_density_wasserstein(const afiv_grid *g, const double *model_ratio, int64_t C,
+                             const double *market_ratio, int64_t D, double *scratch, double *dist_out,
+                             void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (C < 0 || D < 0 || g->v.nK < 3) return AFIV_E_SHAPE;
+    if (C == 0 || D == 0) return AFIV_OK;
+    if (!model_ratio || !market_ratio || !scratch || !dist_out) return AFIV_E_NULL;
+    return afiv_launch_density_wasserstein(g->v, model_ratio, C, market_ratio, D, scratch, dist_out,
+                                           as_stream(stream));
+}
+
 int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int64_t points,
                         double *stats_out, void *stream)
 {

@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int STAT_THREADS = 256;
+constexpr int MAX_POINTS = AFIV_MAX_STRIKES * AFIV_MAX_MATURITIES;
 
 // numpy/lib/_function_base_impl.py, method "linear": virtual index (n - 1) q, then _get_indexes,
 // _get_gamma and _lerp for one quantile q of m sorted values v.
@@ -110,7 +111,130 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__
     }
 }
 
+// ---- density-Wasserstein term of the calibration's second stage -------------------------------
+// run_single_heston_calibration.py:100-151 for every (candidate, day, maturity).  Both sides go
+// through the same steps -- second differences of the price ratios on the fine strike grid,
+// times exp(r tau), clipped at zero, normalised -- and scipy.stats.wasserstein_distance on a common
+// support reduces to sum_i |U_i - V_i| (x_{i+1} - x_i) with U, V the normalised cumulative
+// weights.  So each side is turned into its CDF once (density_cdf_kernel, one thread per
+// (set, maturity)) and the distance matrix is an L1 distance between CDF rows.
+//
+// status per (set, maturity): 0 = usable, 1 = the reference returns inf (model ratio NaN or
+// negative, :118-119, or a density that sums to < 1e-10, :139-140), 2 = maturity absent (NaN
+// row: the caller marks maturities with fewer than 3 market points this way, :375-377).
+
+// np.sum of n <= 128 doubles: NumPy's pairwise routine with 8 running sums.
+__device__ double numpy_sum_small(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__global__ __launch_bounds__(64) void density_cdf_kernel(GridView g, const double *__restrict__ ratio, int64_t M,
+                                                         int is_model, double *__restrict__ cdf,
+                                                         double *__restrict__ status)
+{
+    const int nT = g.nT, nK = g.nK;
+    const int64_t item = (int64_t)blockIdx.x * 64 + threadIdx.x;       // (set, maturity)
+    if (item >= M * nT) return;
+    const int t = (int)(item % nT);
+    const double *pr = ratio + item * nK;
+    double *out = cdf + item * nK;
+    double dens[AFIV_MAX_STRIKES];
+    bool any_nan = false, any_neg = false;
+    for (int i = 0; i < nK; ++i) {
+        const double v = pr[i];
+        any_nan |= v != v;
+        any_neg |= v < 0;
+    }
+    double st = 0.0;
+    if (is_model ? (any_nan || any_neg) : false) st = 1.0;
+    if (!is_model && any_nan) st = 2.0;
+    if (st == 0.0) {
+        const double dlm = g.logm[1] - g.logm[0];
+        const double scale = exp(g.r * g.tau[t]);
+        dens[0] = 0.0;
+        dens[nK - 1] = 0.0;
+        for (int i = 1; i + 1 < nK; ++i) {
+            const double d2 = (pr[i + 1] - 2 * pr[i] + pr[i - 1]) / (dlm * dlm);
+            dens[i] = fmax(scale * d2, 0.0);
+        }
+        const double total = numpy_sum_small(dens, nK);
+        if (total < 1e-10) {
+            st = 1.0;
+        } else {
+            for (int i = 0; i < nK; ++i) dens[i] = dens[i] / total;
+            // cumulative weights, then divided by the last one as scipy's _cdf_distance does
+            double run = 0.0;
+            for (int i = 0; i < nK; ++i) { run += dens[i]; dens[i] = run; }
+            for (int i = 0; i < nK; ++i) out[i] = dens[i] / run;
+        }
+    }
+    status[item] = st;
+}
+
+__global__ __launch_bounds__(256) void wasserstein_kernel(GridView g, const double *__restrict__ cdf_model,
+                                                          const double *__restrict__ st_model, int64_t C,
+                                                          const double *__restrict__ cdf_market,
+                                                          const double *__restrict__ st_market, int64_t D,
+                                                          double *__restrict__ dist)
+{
+    __shared__ double model[MAX_POINTS];
+    __shared__ double stm[AFIV_MAX_MATURITIES];
+    __shared__ double dx[AFIV_MAX_STRIKES];
+    const int nT = g.nT, nK = g.nK, per = nT * nK;
+    for (int k = threadIdx.x; k + 1 < nK; k += 256) dx[k] = g.logm[k + 1] - g.logm[k];
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += 256) model[i] = cdf_model[c * per + i];
+        for (int t = threadIdx.x; t < nT; t += 256) stm[t] = st_model[c * nT + t];
+        __syncthreads();
+        for (int64_t item = threadIdx.x; item < D * nT; item += 256) {
+            const int t = (int)(item % nT);
+            const double sm = stm[t], sk = st_market[item];
+            double w;
+            if (sk == 2.0) w = __builtin_nan("");
+            else if (sm != 0.0 || sk != 0.0) w = __builtin_inf();
+            else {
+                const double *u = cdf_market + item * nK;
+                const double *v = model + t * nK;
+                w = 0.0;
+                for (int i = 0; i + 1 < nK; ++i) w += fabs(u[i] - v[i]) * dx[i];
+            }
+            dist[c * D * nT + item] = w;
+        }
+    }
+}
+
 }  // namespace
+
+int afiv_launch_density_wasserstein(const GridView &g, const double *model_ratio, int64_t C,
+                                    const double *market_ratio, int64_t D, double *scratch, double *dist,
+                                    hipStream_t s)
+{
+    const int64_t per = (int64_t)g.nT * g.nK;
+    double *cdf_model = scratch, *cdf_market = cdf_model + C * per;
+    double *st_model = cdf_market + D * per, *st_market = st_model + C * g.nT;
+    hipLaunchKernelGGL(density_cdf_kernel, dim3((unsigned)((C * g.nT + 63) / 64)), dim3(64), 0, s, g, model_ratio, C, 1,
+                       cdf_model, st_model);
+    hipLaunchKernelGGL(density_cdf_kernel, dim3((unsigned)((D * g.nT + 63) / 64)), dim3(64), 0, s, g, market_ratio, D, 0,
+                       cdf_market, st_market);
+    const int64_t blocks = C < 4096 ? C : 4096;
+    hipLaunchKernelGGL(wasserstein_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, cdf_model, st_model, C, cdf_market,
+                       st_market, D, dist);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
                          hipStream_t s)

@@ -158,6 +158,19 @@ int afiv_stage1_objective(const afiv_grid *g, const double *model_ratio, const d
                           int64_t C, const double *market_ratio, int64_t D, double drift_weight,
                           double *loss_out, void *stream);
 
+/* ---- calibration Stage-2 density term: replaces compute_density_wasserstein
+ * (run_single_heston_calibration.py:100-151) for C candidates against D days, per maturity.
+ * g is the FINE grid: its strikes are the n_points log-moneyness values of :107 (at least 3,
+ * equally spaced), its maturities those of the surface.  model_ratio: device [C,nT,nK] from
+ * afiv_price on g; market_ratio: device [D,nT,nK] = the day's market ratios interpolated to the
+ * fine strikes (:110), a maturity the reference skips (< 3 market points, :375-377) filled with
+ * NaN.  scratch: device [(C+D)*nT*(nK+1)] doubles.  dist_out: device [C,D,nT] = the Wasserstein
+ * distance, +inf where the reference returns inf (:116-119, :139-140), NaN for skipped
+ * maturities; objective_stage2 (:342-406) averages the finite entries of a row. */
+int afiv_density_wasserstein(const afiv_grid *g, const double *model_ratio, int64_t C,
+                             const double *market_ratio, int64_t D, double *scratch,
+                             double *dist_out, void *stream);
+
 /* ---- ensemble statistics: replaces generate_iv_surface_by_date.py:474-478, i.e.
  * np.nanmean, np.nanmedian, np.nanpercentile(5) and np.nanpercentile(95) over axis 0 of the
  * stacked valid surfaces (NumPy's default "linear" percentile method, bit for bit).

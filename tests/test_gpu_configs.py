@@ -248,3 +248,77 @@ def test_config5_stress_grid(afiv):
         assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, max_ill_mismatch=0.01)
     flags = grid.arb_check(dev(iv_o), dev(ratio), SPOT, "B").cpu().numpy()
     assert np.array_equal(flags, oracle.arb_check(iv_o, ratio, LOGM_GRID, tau, SPOT, R, Q, "B"))
+
+
+def test_config4_stage2_density_wasserstein(afiv, golden_dir):
+    """run_single_heston_calibration.py:100-151 / :342-406 on the fine strike grid, against the
+    NumPy/SciPy restatement (scipy.stats.wasserstein_distance itself)."""
+    pin = np.load(f"{golden_dir}/calibration_pin.npz")
+    t_grid, logm_grid = pin["T_grid"], pin["logm_grid"]
+    r, q = float(pin["r"]), float(pin["q"])
+    n_points = int(pin["density_grid_points"])
+    days = pin["iv_surfaces"][::25]                              # 20 days
+    market = market_lattice(days, t_grid, logm_grid, r, q)
+    fine = np.linspace(logm_grid.min(), logm_grid.max(), n_points)
+    market_fine = np.full((len(days), len(t_grid), n_points), np.nan)
+    for d in range(len(days)):
+        for m in range(len(t_grid)):
+            mask = ~np.isnan(market[d, m])
+            if mask.sum() >= 3:
+                # every maturity of every day in the data spans the full strike range
+                assert logm_grid[mask].min() == logm_grid.min() and logm_grid[mask].max() == logm_grid.max()
+                market_fine[d, m] = np.interp(fine, logm_grid[mask], market[d, m][mask])
+    market_fine[3, 2] = np.nan                                   # a maturity the reference would skip
+    cand = sample_params(24, 8)
+    cand[:8] = pin["params"][:8]
+    grid_fine = afiv.Grid(fine, t_grid, r, q)
+    model_fine = grid_fine.price(dev(cand))
+    dist = grid_fine.density_wasserstein(model_fine, dev(market_fine)).cpu().numpy()
+    assert dist.shape == (24, len(days), len(t_grid))
+    assert np.all(np.isnan(dist[:, 3, 2]))
+    model_h = model_fine.cpu().numpy()
+    from scipy.stats import wasserstein_distance
+
+    def reference_distance(mdl, mkt, tau):
+        # the body of compute_density_wasserstein after the two price vectors are known
+        if np.any(np.isnan(mdl)) or np.any(mdl < 0):
+            return np.inf
+        dlm = fine[1] - fine[0]
+        md, dd = np.zeros(n_points), np.zeros(n_points)
+        for i in range(1, n_points - 1):
+            md[i] = np.exp(r * tau) * ((mkt[i + 1] - 2 * mkt[i] + mkt[i - 1]) / dlm ** 2)
+            dd[i] = np.exp(r * tau) * ((mdl[i + 1] - 2 * mdl[i] + mdl[i - 1]) / dlm ** 2)
+        md, dd = np.maximum(md, 0), np.maximum(dd, 0)
+        if md.sum() < 1e-10 or dd.sum() < 1e-10:
+            return np.inf
+        return wasserstein_distance(fine, fine, md / md.sum(), dd / dd.sum())
+
+    n_inf = 0
+    for c in range(24):
+        for d in range(len(days)):
+            for m in range(len(t_grid)):
+                if d == 3 and m == 2:
+                    continue
+                ref = reference_distance(model_h[c, m], market_fine[d, m], t_grid[m])
+                got = dist[c, d, m]
+                if np.isinf(ref):
+                    assert np.isinf(got), (c, d, m)
+                    n_inf += 1
+                else:
+                    assert abs(got - ref) <= 1e-12 * max(1.0, abs(ref)) + 1e-15, (c, d, m, got, ref)
+    # the restatement in oracle/ prices the fine grid itself: end to end for two calibrated sets
+    for c in (0, 1):
+        lm_valid = logm_grid
+        w = oracle.density_wasserstein(cand[c], lm_valid, t_grid[4], market[0, 4], r, q, n_points)
+        if np.isfinite(w) and np.isfinite(dist[c, 0, 4]):
+            assert abs(dist[c, 0, 4] - w) <= 1e-6 * max(1.0, abs(w))
+    # Stage-2 total = Stage-1 loss + weight * mean of the finite distances, 1e10 passes through
+    grid = afiv.Grid(logm_grid, t_grid, r, q)
+    base = grid.stage1_objective(grid.price(dev(cand)), dev(cand), dev(market), float(pin["drift_weight"]))
+    total = grid_fine.stage2_objective(base, dev(dist), float(pin["wasserstein_weight"])).cpu().numpy()
+    base_h = base.cpu().numpy()
+    for c in (0, 5, 20):
+        for d in (0, 3, 7):
+            fin = dist[c, d][np.isfinite(dist[c, d])]
+            want = 1e10 if base_h[c, d] >= 1e10 else base_h[c, d] + float(pin["wasserstein_weight"]) * (fin.mean() if fin.size else 0.0)
+            assert abs(total[c, d] - want) <= 1e-12 * max(1.0, abs(want))
