@@ -117,6 +117,31 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     v.disc_tau = v.Dr + nT; v.fwd_mult = v.disc_tau + nT; v.dq_tau = v.fwd_mult + nT;
     v.logm = v.dq_tau + nT; v.Kmult = v.logm + nK; v.tab = v.Kmult + nK;
     v.point = dev + n_const;
+    // whole-day year fractions with at most two distinct increments: see price_kernel's NFAC
+    v.step_count = 0;
+    v.step_dt[0] = v.step_dt[1] = 0.0;
+    v.step_sel = 0;
+    if (trunc_days && nT >= 4 && nT <= 32) {
+        long lo = 0, hi = 0;
+        bool ok = (long)(tau[0] * 365.0) >= 0;
+        for (int t = 1; t < nT && ok; ++t) {
+            const long d = (long)(tau[t] * 365.0) - (long)(tau[t - 1] * 365.0);
+            if (d <= 0) ok = false;
+            if (t == 1 || d < lo) lo = d;
+            if (t == 1 || d > hi) hi = d;
+        }
+        if (ok && hi - lo <= 3) {
+            unsigned long long sel = 0;
+            for (int t = 1; t < nT; ++t) {
+                const long d = (long)(tau[t] * 365.0) - (long)(tau[t - 1] * 365.0);
+                sel |= (unsigned long long)(d - lo) << (2 * t);
+            }
+            v.step_count = hi == lo ? 1 : 2;
+            v.step_dt[0] = (double)lo / 365.0;
+            v.step_dt[1] = 1.0 / 365.0;
+            v.step_sel = sel;
+        }
+    }
     *out = g;
     return AFIV_OK;
 }

@@ -25,6 +25,12 @@ struct GridView {
     const double *logm;       // [nK]
     const double *Kmult;      // [nK] exp(logm)
     const double *tab;        // [AFIV_KDIM][nKpad] strike tables, see afiv_price.hip
+    // Regular term structures (afiv_price.hip, NFAC): step_count = 0 (none), 1 (successive year
+    // fractions are step_dt[0] apart) or 2 (step_dt[0] plus k times step_dt[1] = one day, k <= 3 in
+    // bits 2t, 2t+1 of step_sel for the step from maturity t-1 to t).
+    int step_count;
+    double step_dt[2];
+    unsigned long long step_sel;
     double *point;            // [nT*nK][4] per-call table of the implied-vol kernel (log F/K and the
                               // Black-Scholes values at the bracket ends for the call's spot);
                               // rewritten by every implied-vol call, so calls on one grid must

@@ -138,15 +138,20 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
     return s;
 }
 
-// One characteristic-function evaluation: returns (E sin alpha, E cos alpha) with the discount
-// factor of its integral folded in.
-__device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, double phi, double wp,
-                                           double T, double ddt, double disc)
+// exp(-d T)
+__device__ __forceinline__ Cx cexp_neg(Cx d, double T)
 {
-    const double er = afivm::exp_core_f64(-s.d.r * T);
+    const double er = afivm::exp_core_f64(-d.r * T);
     double sn, cs;
-    afivm::sincos_f64(s.d.i * T, &sn, &cs);
-    const Cx ex = {er * cs, -er * sn};               // exp(-d T)
+    afivm::sincos_f64(d.i * T, &sn, &cs);
+    return {er * cs, -er * sn};
+}
+
+// One characteristic-function evaluation given ex = exp(-d T): returns (E sin alpha, E cos alpha)
+// with the discount factor of its integral folded in.
+__device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, double phi, double wp,
+                                           double T, double ddt, double disc, Cx ex)
+{
     const Cx omex = {1.0 - ex.r, -ex.i};             // 1 - ex
     const Cx pe = cmul(s.p, ex);
     const Cx num = {1.0 - pe.r, -pe.i};              // 1 - p ex
@@ -174,7 +179,15 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
 
 // NCTP = column tiles rounded up to a power of two (1, 2, 4); the 16 waves split into NCTP column
 // tiles x (16/NCTP) ranges of the 576-long contraction.
-template <int NCTP>
+//
+// NFAC = 0: exp(-d T) is evaluated for every maturity (one exp and one sincos).  NFAC = 1, 2: the
+// year fractions are whole days / 365 and successive maturities are base + k days apart with
+// k = 0 (NFAC = 1) or k <= 3 (NFAC = 2) -- a regular term structure such as
+// round(linspace(30, 730, 20)) days, truncated as the reference truncates, steps by 36..38 days
+// -- so exp(-d T_t) = exp(-d T_{t-1}) exp(-d base/365) exp(-d/365)^k costs 1 + k complex
+// multiplications per maturity; the thread keeps the two factors.  Some 40 multiplications add
+// rounding of a few eps to a factor that is evaluated to 2 ulp otherwise.
+template <int NCTP, int NFAC>
 __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double *__restrict__ params,
                                                         int64_t N, double *__restrict__ ratio_out)
 {
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
 
     Model m = {};
     JState st0 = {}, st1 = {};
+    Cx ex0 = {}, ex1 = {}, fa0 = {}, fa1 = {}, fb0 = {}, fb1 = {};   // NFAC > 0: running exp(-d T), step factors
     int64_t prev_chunk = 0;
     int prev_tile = 0;
 
@@ -227,6 +241,17 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             m.c2 = m.main_branch ? (kappa * theta) / m.sigma2 : kappa * theta;
             st0 = cf_setup<0>(kappa, sigma, rho, m, phi);
             st1 = cf_setup<1>(kappa, sigma, rho, m, phi);
+            if (NFAC > 0) {
+                const double T0 = g.term[0];
+                ex0 = cexp_neg(st0.d, T0);
+                ex1 = cexp_neg(st1.d, T0);
+                fa0 = cexp_neg(st0.d, g.step_dt[0]);
+                fa1 = cexp_neg(st1.d, g.step_dt[0]);
+                if (NFAC > 1) {
+                    fb0 = cexp_neg(st0.d, g.step_dt[1]);
+                    fb1 = cexp_neg(st1.d, g.step_dt[1]);
+                }
+            }
         }
 
         v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -281,16 +306,32 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             const int t = tile * MT + tl;
             tn = min(t + 1, nT - 1);
             Tn = g.term[tn]; ddn = g.dd[tn]; Dqn = g.Dq[tn]; Drn = g.Dr[tn];
+            // extra days on top of the base step that lead to maturity t (wave-uniform)
+            const int extra = NFAC > 1 ? (int)((g.step_sel >> (2 * t)) & 3ull) : 0;
             if (have_cur) {
                 double2 x0 = make_double2(0.0, 0.0);
-                if (t < nT) x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq);
+                if (t < nT) {
+                    if (NFAC == 0) ex0 = cexp_neg(st0.d, T);
+                    else if (t > 0) {
+                        ex0 = cmul(ex0, fa0);
+                        for (int e = 0; e < extra; ++e) ex0 = cmul(ex0, fb0);
+                    }
+                    x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq, ex0);
+                }
                 if (sl < SPB)     // spare lanes of the last wave own no row
                     *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * n]) = x0;
             }
             if (do_mfma && 2 * tl == my_slot) mfma_chain();
             if (have_cur) {
                 double2 x1 = make_double2(0.0, 0.0);
-                if (t < nT) x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr);
+                if (t < nT) {
+                    if (NFAC == 0) ex1 = cexp_neg(st1.d, T);
+                    else if (t > 0) {
+                        ex1 = cmul(ex1, fa1);
+                        for (int e = 0; e < extra; ++e) ex1 = cmul(ex1, fb1);
+                    }
+                    x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr, ex1);
+                }
                 if (sl < SPB)
                     *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * (NQ + n)]) = x1;
             }
@@ -366,8 +407,17 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     // one workgroup per CU is resident (LDS); a few waves of workgroups per CU balance the tail
     const int64_t blocks = chunks < 256 * 8 ? chunks : 256 * 8;
     dim3 grid((unsigned)blocks), block(THREADS);
-    if (nct == 1) hipLaunchKernelGGL(price_kernel<1>, grid, block, 0, s, g, params, N, ratio_out);
-    else if (nct == 2) hipLaunchKernelGGL(price_kernel<2>, grid, block, 0, s, g, params, N, ratio_out);
-    else hipLaunchKernelGGL(price_kernel<4>, grid, block, 0, s, g, params, N, ratio_out);
+#define AFIV_LAUNCH_PRICE(NCT, NF) hipLaunchKernelGGL((price_kernel<NCT, NF>), grid, block, 0, s, g, params, N, ratio_out)
+#define AFIV_LAUNCH_PRICE_NF(NCT)                        \
+    do {                                                 \
+        if (g.step_count == 1) AFIV_LAUNCH_PRICE(NCT, 1); \
+        else if (g.step_count == 2) AFIV_LAUNCH_PRICE(NCT, 2); \
+        else AFIV_LAUNCH_PRICE(NCT, 0);                  \
+    } while (0)
+    if (nct == 1) AFIV_LAUNCH_PRICE_NF(1);
+    else if (nct == 2) AFIV_LAUNCH_PRICE_NF(2);
+    else AFIV_LAUNCH_PRICE_NF(4);
+#undef AFIV_LAUNCH_PRICE_NF
+#undef AFIV_LAUNCH_PRICE
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
