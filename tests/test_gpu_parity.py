@@ -386,3 +386,41 @@ def test_price_against_50_digit_quadrature_at_small_vol_of_vol(afiv, golden_dir)
     orc = oracle.price_ratio_grid(g["params"], g["logm"], g["tau"], float(g["r"]), float(g["q"]))
     assert np.all(np.abs(orc - ref) <= price_tol(ref, g["params"]))
     assert np.abs(orc - ref).max() > 100 * np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("days", [
+    [30, 60, 90, 120, 150, 180],                      # one increment: one step factor
+    [30, 67, 104, 141, 177, 214, 250, 288, 325],      # 36..38 days: base step plus one-day factors
+    [10, 13, 16, 20, 23, 26, 29, 33],                 # base 3 days, up to 1 extra
+    [30, 60, 91, 182, 273, 365, 547, 730],            # irregular: every maturity evaluated directly
+])
+def test_price_regular_and_irregular_term_structures(afiv, days):
+    """Whole-day year fractions take the stepped evaluation of exp(-d T) when the increments allow
+    it; every mode meets the same bound against the oracle."""
+    tau = (np.array(days) + 0.5) / 365.0              # truncates to `days` (heston_model_ql.py:131)
+    assert [int(t * 365.0) for t in tau] == days
+    logm = np.linspace(-0.15, 0.15, 7)
+    grid = afiv.Grid(logm, tau, R, Q)
+    p = sample_params(96, 31)
+    got = grid.price(dev(p)).cpu().numpy()
+    ref = oracle.price_ratio_grid(p, logm, tau, R, Q)
+    err = np.abs(got - ref) / price_tol(ref, p)
+    assert np.all(err <= 1.0), f"max excess {err.max():.3g}"
+    big = p[:, 2] >= 0.06
+    assert np.all(np.abs(got - ref)[big] <= price_tol(ref[big]))
+
+
+def test_stepped_exponential_agrees_with_direct_evaluation(afiv):
+    """The same maturities priced through the stepped mode (a 20-maturity regular grid) and
+    directly (3-maturity grids are always evaluated directly) agree to rounding: the running
+    product of step factors adds some 1e-14 at most."""
+    days = [30, 67, 104, 141, 177, 214, 250, 288, 325, 362, 398, 435, 472, 509, 546, 583, 619, 656, 693, 730]
+    tau = (np.array(days) + 0.5) / 365.0
+    logm = np.linspace(-0.2, 0.2, 9)
+    p = dev(sample_params(64, 41))
+    full = afiv.Grid(logm, tau, R, Q).price(p).cpu().numpy()
+    worst = 0.0
+    for lo in (0, 9, 17):
+        sub = afiv.Grid(logm, tau[lo:lo + 3], R, Q).price(p).cpu().numpy()
+        worst = max(worst, float(np.abs(sub - full[:, lo:lo + 3]).max()))
+    assert worst <= 2e-13, worst
