@@ -72,6 +72,7 @@ struct BsPoint {
     double logm, rq;  // logm, r - q                    (variant B)
     double tau, sqrt_tau;
     double target;    // heston price
+    double ratio;     // exp(-d2^2/2) / exp(-d1^2/2): F/K (variant A), exp(logm + (r-q) tau) (variant B)
 };
 
 // n / d through the hardware reciprocal, two Newton steps and one residual correction: the
@@ -84,6 +85,53 @@ __device__ __forceinline__ double fdivq(double n, double d)
     const double q = n * r;
     const double e = __builtin_fma(-d, q, n);
     return __builtin_fma(e, r, q);
+}
+
+// erfcx(u) for u >= 0 from the LDS table (the polynomial part of ndtr_dev)
+__device__ __forceinline__ double erfcx_dev(double u, const double *__restrict__ tab)
+{
+    const double t = 64.0 * afivm::rcp_f64(1.0 + u);
+    const int seg = (int)fmin(t, 63.0);
+    const double f = (t - (double)seg) - 0.5;
+    const double *c = tab + seg * ERFCX_ROW;
+    double p = c[8];
+    p = fma(p, f, c[7]);
+    p = fma(p, f, c[6]);
+    p = fma(p, f, c[5]);
+    p = fma(p, f, c[4]);
+    p = fma(p, f, c[3]);
+    p = fma(p, f, c[2]);
+    p = fma(p, f, c[1]);
+    return fma(p, f, c[0]);
+}
+
+// The root finder's objective (without the target): the Black-Scholes value at a vol from the
+// bracket (finite, > 0: no NaN handling, no IEEE special cases in the quotient).  Both normal
+// CDFs share ONE exponential: exp(-d2^2/2) = exp(-d1^2/2) c.ratio, the identity
+// F phi(d1) = K phi(d2) of the formula itself, so N(d2) costs its erfcx polynomial only.
+template <int VARIANT>
+__device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, const double *__restrict__ tab,
+                                               const afivm::ExpCoef &ec)
+{
+    const double sqrth = 7.07106781186547524401E-1;
+    double num;
+    if (VARIANT == AFIV_VARIANT_A) num = c.lnFK + 0.5 * (iv * iv) * c.tau;
+    else num = c.logm + (c.rq + 0.5 * (iv * iv)) * c.tau;
+    const double den = iv * c.sqrt_tau;
+    const double d1 = fdivq(num, den);
+    const double d2 = d1 - den;
+    const double x1 = d1 * sqrth, x2 = d2 * sqrth;
+    const double u1 = fabs(x1), u2 = fabs(x2);
+    const double p1 = erfcx_dev(u1, tab), p2 = erfcx_dev(u2, tab);
+    const double s = u1 * u1;
+    const double lo = fma(u1, u1, -s);              // exact low part of the square
+    double e = afivm::exp_core_f64(-s, ec);
+    e = 0.5 * fma(-e, lo, e);                       // exp(-u1^2) / 2
+    const double h1 = e * p1, h2 = (e * c.ratio) * p2;
+    const double n1 = x1 > 0 ? 1.0 - h1 : h1;
+    const double n2 = x2 > 0 ? 1.0 - h2 : h2;
+    if (VARIANT == AFIV_VARIANT_A) return c.disc * (c.F * n1 - c.K * n2);
+    return c.sdq * n1 - c.kdr * n2;
 }
 
 // FAST: vols come from a root finder's bracket (finite, > 0), so the normal CDF needs no NaN
@@ -105,7 +153,7 @@ __device__ __forceinline__ double bs_price(const BsPoint &c, double iv, const do
     }
 }
 
-__device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, double spot)
+__device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, double spot, int variant)
 {
     BsPoint c;
     c.tau = g.tau[t];
@@ -119,6 +167,7 @@ __device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, d
     c.logm = g.logm[k];
     c.rq = g.r - g.q;
     c.target = 0.0;
+    c.ratio = variant == AFIV_VARIANT_A ? c.F / c.K : g.Kmult[k] * g.fwd_mult[t];
     return c;
 }
 
@@ -161,7 +210,7 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
             const double x = v[i];
             if (isnan(x)) { n_nan++; n_bad++; }
             else if (x <= 0) n_bad++;
-            BsPoint c = make_point(g, t, k, spot);
+            BsPoint c = make_point(g, t, k, spot, BSFORM);
             price[i] = bs_price<BSFORM>(c, x, tab);
             if (pr) {
                 const double y = pr[i];
@@ -241,7 +290,7 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
 // taken from Brent's last objective value (objective + target, exact at a root), so the static
 // and calendar checks cost no further normal CDFs.  Vols go straight to global memory.
 struct MatRow { double tau, sqrt_tau, disc, F, sdq; };
-struct __attribute__((aligned(32))) PointRow { double lnfk, fa, fb, pad; };
+struct __attribute__((aligned(32))) PointRow { double lnfk, fa, fb, ratio; };
 
 constexpr double BRENT_XA = 0.001, BRENT_XB = 3.0, BRENT_XTOL = 1e-6, BRENT_RTOL = 4 * 2.220446049250313e-16;
 constexpr int BRENT_MAXITER = 100;
@@ -257,12 +306,13 @@ __global__ __launch_bounds__(256) void point_table_kernel(GridView g, double spo
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= per) return;
     const int t = i / g.nK, k = i - t * g.nK;
-    const BsPoint c = make_point(g, t, k, spot);
+    const BsPoint c = make_point(g, t, k, spot, VARIANT);
     PointRow row;
     row.lnfk = c.lnFK;
-    row.fa = bs_price<VARIANT, true>(c, BRENT_XA, tab);
-    row.fb = bs_price<VARIANT, true>(c, BRENT_XB, tab);
-    row.pad = 0.0;
+    const afivm::ExpCoef ec = afivm::load_exp_coef();
+    row.fa = bs_objective<VARIANT>(c, BRENT_XA, tab, ec);
+    row.fb = bs_objective<VARIANT>(c, BRENT_XB, tab, ec);
+    row.ratio = c.ratio;
     reinterpret_cast<PointRow *>(g.point)[i] = row;
 }
 
@@ -330,6 +380,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
     const float inv_nT = 1.0f / (float)nT, inv_nK = 1.0f / (float)nK;
     const double nan = __builtin_nan("");
     const double rq = g.r - g.q;
+    const afivm::ExpCoef ec = afivm::load_exp_coef();
     const double xa = BRENT_XA, xb = BRENT_XB, xtol = BRENT_XTOL, rtol = BRENT_RTOL;
 
     for (int64_t s = (int64_t)blockIdx.x * NG + gid; s < N; s += (int64_t)gridDim.x * NG) {
@@ -413,6 +464,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                         c.logm = logm[k];
                         c.rq = rq;
                         c.lnFK = pt.lnfk;
+                        c.ratio = pt.ratio;
                         const double y = price[i_cur];
                         const double hp = y * spot * c.disc;
                         c.target = hp;
@@ -470,7 +522,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 xcur += fabs(scur) > delta ? scur : sd;
             }
 
-            const double f = bs_price<VARIANT, true>(c, xcur, tab) - c.target;
+            const double f = bs_objective<VARIANT>(c, xcur, tab, ec) - c.target;
 
             // -- first half of the next pass: re-bracket, order, convergence test
             if (phase == PH_ITER) {

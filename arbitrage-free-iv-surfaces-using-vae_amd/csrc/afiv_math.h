@@ -100,6 +100,32 @@ __device__ __forceinline__ double exp_core_f64(double x)
     return __builtin_ldexp(p, (int)k);                          // v_ldexp_f64: exact scaling, graceful underflow
 }
 
+// The same with the coefficients in caller-held registers: a kernel with scalar registers to
+// spare loads them once (load_exp_coef) instead of fetching them at every call.
+struct ExpCoef { double c[12]; };   // x^2 ... x^13
+
+__device__ __forceinline__ ExpCoef load_exp_coef()
+{
+    const coef_ptr c_exp = coeffs_hoistable() + OFF_EXP;
+    ExpCoef k;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) k.c[i] = c_exp[i + 2];
+    return k;
+}
+
+__device__ __forceinline__ double exp_core_f64(double x, const ExpCoef &k)
+{
+    const double n = __builtin_rint(x * AFIV_LOG2E);
+    double r = __builtin_fma(n, -AFIV_LN2_HI, x);
+    r = __builtin_fma(n, -AFIV_LN2_LO, r);
+    double p = k.c[11];
+#pragma unroll
+    for (int i = 10; i >= 0; --i) p = fma_sc(p, r, k.c[i]);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 template <bool PINNED = true>
 __device__ __forceinline__ double exp_f64(double x)
 {
