@@ -87,28 +87,37 @@ __device__ __forceinline__ double fdivq(double n, double d)
     return __builtin_fma(e, r, q);
 }
 
-// erfcx(u) for u >= 0 from the LDS table (the polynomial part of ndtr_dev)
-__device__ __forceinline__ double erfcx_dev(double u, const double *__restrict__ tab)
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// Segment and local coordinate of erfcx's table for u >= 0 (see ndtr_dev).
+__device__ __forceinline__ const d2v *erfcx_row(double u, const double *__restrict__ tab, double *f)
 {
     const double t = 64.0 * afivm::rcp_f64(1.0 + u);
     const int seg = (int)fmin(t, 63.0);
-    const double f = (t - (double)seg) - 0.5;
-    const double *c = tab + seg * ERFCX_ROW;
-    double p = c[8];
-    p = fma(p, f, c[7]);
-    p = fma(p, f, c[6]);
-    p = fma(p, f, c[5]);
-    p = fma(p, f, c[4]);
-    p = fma(p, f, c[3]);
-    p = fma(p, f, c[2]);
-    p = fma(p, f, c[1]);
-    return fma(p, f, c[0]);
+    *f = (t - (double)seg) - 0.5;
+    return reinterpret_cast<const d2v *>(tab + seg * ERFCX_ROW);      // rows are 80 bytes: 16-byte aligned
+}
+
+__device__ __forceinline__ double erfcx_horner(d2v q0, d2v q1, d2v q2, d2v q3, double q4, double f)
+{
+    double p = q4;
+    p = fma(p, f, q3.y);
+    p = fma(p, f, q3.x);
+    p = fma(p, f, q2.y);
+    p = fma(p, f, q2.x);
+    p = fma(p, f, q1.y);
+    p = fma(p, f, q1.x);
+    p = fma(p, f, q0.y);
+    return fma(p, f, q0.x);
 }
 
 // The root finder's objective (without the target): the Black-Scholes value at a vol from the
 // bracket (finite, > 0: no NaN handling, no IEEE special cases in the quotient).  Both normal
 // CDFs share ONE exponential: exp(-d2^2/2) = exp(-d1^2/2) c.ratio, the identity
-// F phi(d1) = K phi(d2) of the formula itself, so N(d2) costs its erfcx polynomial only.
+// F phi(d1) = K phi(d2) of the formula itself, so N(d2) costs its erfcx polynomial only.  The
+// ten table reads of the two polynomials are issued together, ahead of the exponential, so that
+// their LDS latency is paid once and under that arithmetic (left to the compiler they are sunk
+// next to their uses, one wait per coefficient pair).
 template <int VARIANT>
 __device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, const double *__restrict__ tab,
                                                const afivm::ExpCoef &ec)
@@ -122,11 +131,20 @@ __device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, cons
     const double d2 = d1 - den;
     const double x1 = d1 * sqrth, x2 = d2 * sqrth;
     const double u1 = fabs(x1), u2 = fabs(x2);
-    const double p1 = erfcx_dev(u1, tab), p2 = erfcx_dev(u2, tab);
+    double f1, f2;
+    const d2v *r1 = erfcx_row(u1, tab, &f1);
+    const d2v *r2 = erfcx_row(u2, tab, &f2);
+    const d2v a0 = r1[0], a1 = r1[1], a2 = r1[2], a3 = r1[3];
+    const double a4 = reinterpret_cast<const double *>(r1)[8];
+    const d2v b0 = r2[0], b1 = r2[1], b2 = r2[2], b3 = r2[3];
+    const double b4 = reinterpret_cast<const double *>(r2)[8];
+    __builtin_amdgcn_sched_barrier(0);
     const double s = u1 * u1;
     const double lo = fma(u1, u1, -s);              // exact low part of the square
     double e = afivm::exp_core_f64(-s, ec);
     e = 0.5 * fma(-e, lo, e);                       // exp(-u1^2) / 2
+    const double p1 = erfcx_horner(a0, a1, a2, a3, a4, f1);
+    const double p2 = erfcx_horner(b0, b1, b2, b3, b4, f2);
     const double h1 = e * p1, h2 = (e * c.ratio) * p2;
     const double n1 = x1 > 0 ? 1.0 - h1 : h1;
     const double n2 = x2 > 0 ? 1.0 - h2 : h2;
@@ -522,7 +540,10 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 xcur += fabs(scur) > delta ? scur : sd;
             }
 
-            const double f = bs_objective<VARIANT>(c, xcur, tab, ec) - c.target;
+            double f = bs_objective<VARIANT>(c, xcur, tab, ec) - c.target;
+            // pin the evaluation here: its only reader is the conditional block below, and sunk
+            // into it the table reads would no longer be issued ahead of the exponential
+            asm volatile("" : "+v"(f));
 
             // -- first half of the next pass: re-bracket, order, convergence test
             if (phase == PH_ITER) {
