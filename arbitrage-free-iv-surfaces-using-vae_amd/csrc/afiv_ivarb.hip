@@ -191,6 +191,9 @@ __device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, d
 
 // One workgroup per surface.
 constexpr int ARB_THREADS = 256;
+#ifndef AFIV_IV_REFILL_LANES
+#define AFIV_IV_REFILL_LANES 6            // idle lanes of a wave that trigger a refill
+#endif
 #ifndef AFIV_IV_THREADS
 #define AFIV_IV_THREADS 512               // fused kernel, wave-per-surface mode: 8 surfaces in flight per workgroup
 #endif
@@ -448,9 +451,12 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 }
                 phase = PH_IDLE;
             }
+            // Handing out points costs about a third of a trip's instructions whether one lane or
+            // sixty take one, and an idle lane wastes 1/64 of a trip: refill once enough lanes
+            // wait (or nothing else is in flight).
             const bool want = phase == PH_IDLE && !exhausted;
             const unsigned long long wm = __ballot(want);
-            if (wm) {
+            if (wm && (__popcll(wm) >= AFIV_IV_REFILL_LANES || __ballot(phase != PH_IDLE) == 0)) {
                 const int cnt = __popcll(wm);
                 int base;
                 if (GT == 64) {
