@@ -424,3 +424,22 @@ def test_stepped_exponential_agrees_with_direct_evaluation(afiv):
         sub = afiv.Grid(logm, tau[lo:lo + 3], R, Q).price(p).cpu().numpy()
         worst = max(worst, float(np.abs(sub - full[:, lo:lo + 3]).max()))
     assert worst <= 2e-13, worst
+
+
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_wave_per_surface_mode_equals_workgroup_per_surface_mode(afiv, grid821, variant):
+    """Batches of 2048 surfaces or more take the wave-per-surface schedule, smaller ones the
+    workgroup-per-surface schedule; a ragged batch (not a multiple of the surfaces in flight per
+    workgroup) must give the same vols and flags either way."""
+    n = 2051
+    p = sample_params(n, 23)
+    ratio = grid821.price(dev(p))
+    ratio[7, 3, 4] = float("nan")
+    ratio[11] = -1.0                                             # a surface rejected point by point
+    iv_big, fl_big = grid821.implied_vol_checked(ratio, SPOT, variant)
+    halves = [grid821.implied_vol_checked(ratio[a:b].contiguous(), SPOT, variant) for a, b in ((0, 1025), (1025, n))]
+    iv_small = torch.cat([h[0] for h in halves])
+    fl_small = torch.cat([h[1] for h in halves])
+    assert torch.equal(torch.nan_to_num(iv_big, nan=-1.0), torch.nan_to_num(iv_small, nan=-1.0))
+    assert torch.equal(fl_big, fl_small)
+    assert bool(torch.isnan(iv_big[11]).all())
