@@ -167,6 +167,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The surfaces themselves stay sharded while the job runs; if one consumer wants them all, the
+    # vols are gathered ONCE at the end (not part of a step): time that exchange separately.
+    final_gather = None
+    if world > 1 and args.backend == "nccl":
+        iv_all = torch.empty((world * n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        dist.all_gather_into_tensor(iv_all, iv)
+        torch.cuda.synchronize()
+        dist.barrier()
+        final_gather = {"what": "all-gather of the implied vols after the last step (outside the timed steps)",
+                        "bytes_per_rank": iv.numel() * 8, "ms": (time.perf_counter() - tg) * 1e3}
+        del iv_all
+
     k_price = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     k_iv = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
 
@@ -204,6 +219,8 @@ def main():
                       "arbitrage_free_frac": float(np.mean((fl[:, 3] & 1) != 0)),
                       "success_frac": float(np.mean((fl[:, 3] & 8) != 0))},
         }
+        if final_gather is not None:
+            out["final_gather"] = final_gather
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(logm, tau)
         print(json.dumps(out), flush=True)
