@@ -171,16 +171,19 @@ def main():
     # vols are gathered ONCE at the end (not part of a step): time that exchange separately.
     final_gather = None
     if world > 1 and args.backend == "nccl":
-        iv_all = torch.empty((world * n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = time.perf_counter()
-        dist.all_gather_into_tensor(iv_all, iv)
-        torch.cuda.synchronize()
-        dist.barrier()
-        final_gather = {"what": "all-gather of the implied vols after the last step (outside the timed steps)",
-                        "bytes_per_rank": iv.numel() * 8, "ms": (time.perf_counter() - tg) * 1e3}
-        del iv_all
+        try:
+            iv_all = torch.empty((world * n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            dist.all_gather_into_tensor(iv_all, iv)
+            torch.cuda.synchronize()
+            dist.barrier()
+            final_gather = {"what": "all-gather of the implied vols after the last step (outside the timed steps)",
+                            "bytes_per_rank": iv.numel() * 8, "ms": (time.perf_counter() - tg) * 1e3}
+            del iv_all
+        except Exception as exc:   # the headline number must not depend on this optional exchange
+            final_gather = {"error": repr(exc)}
 
     k_price = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     k_iv = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
