@@ -54,12 +54,21 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     // Host-side constants use the host libm so that discount factors, forwards and strikes are
     // the very doubles NumPy produces in the Python reference.
     const size_t n_point = (size_t)4 * nT * nK;     // device-written table, kept 32-byte aligned
-    const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + 3) / 4 * 4;
+    // strikes symmetric about log K = 0 (to a few ulp): half of them carry the contraction
+    const int nH = (nK + 1) / 2, nHpad = (nH + 15) / 16 * 16;
+    bool sym = nK >= 4;
+    double scale = 0.0;
+    for (int k = 0; k < nK; ++k) scale = std::fmax(scale, std::fabs(logm[k]));
+    for (int k = 0; k < nK && sym; ++k)
+        if (!(std::fabs(logm[k] + logm[nK - 1 - k]) <= 8.9e-16 * scale)) sym = false;
+    const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
+    const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
     const size_t nd = n_const + n_point;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
            *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
-           *p_logm = p_dq + nT, *p_K = p_logm + nK, *p_tab = p_K + nK;
+           *p_logm = p_dq + nT, *p_K = p_logm + nK, *p_tab = p_K + nK,
+           *p_sym = p_tab + (size_t)AFIV_KDIM * nKpad;
     for (int t = 0; t < nT; ++t) {
         p_tau[t] = tau[t];
         // heston_model_ql.py:131: int(tau*365) days, Actual/365 Fixed
@@ -93,6 +102,17 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
         }
     }
 
+    if (sym) {
+        for (int k = 0; k < nH; ++k) {
+            const double sx = std::log(p_K[k]);
+            for (int n = 0; n < AFIV_NQ_NODES; ++n) {
+                const double ang = AFIV_LAG_X[n] * sx;
+                p_sym[(size_t)n * nHpad + k] = std::cos(ang);
+                p_sym[(size_t)(AFIV_NQ_NODES + n) * nHpad + k] = std::sin(ang);
+            }
+        }
+    }
+
     afiv_grid *g = new (std::nothrow) afiv_grid();
     if (!g) return AFIV_E_HIP;
     if (hipGetDevice(&g->device) != hipSuccess) { delete g; return AFIV_E_HIP; }
@@ -116,6 +136,10 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     v.tau = dev; v.term = v.tau + nT; v.dd = v.term + nT; v.Dq = v.dd + nT; v.Dr = v.Dq + nT;
     v.disc_tau = v.Dr + nT; v.fwd_mult = v.disc_tau + nT; v.dq_tau = v.fwd_mult + nT;
     v.logm = v.dq_tau + nT; v.Kmult = v.logm + nK; v.tab = v.Kmult + nK;
+    v.sym = sym ? 1 : 0;
+    v.nH = nH;
+    v.nHpad = nHpad;
+    v.tab_sym = v.tab + (size_t)AFIV_KDIM * nKpad;
     v.point = dev + n_const;
     // whole-day year fractions with at most two distinct increments: see price_kernel's NFAC
     v.step_count = 0;

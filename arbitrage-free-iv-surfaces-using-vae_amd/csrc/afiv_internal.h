@@ -25,6 +25,10 @@ struct GridView {
     const double *logm;       // [nK]
     const double *Kmult;      // [nK] exp(logm)
     const double *tab;        // [AFIV_KDIM][nKpad] strike tables, see afiv_price.hip
+    // Symmetric strike grids (log K_k = -log K_{nK-1-k}): sym = 1, nH = (nK + 1)/2 strikes carry
+    // the contraction, nHpad = nH rounded up to 16, tab_sym = [2][144][nHpad]: cos, sin of x_n log K_k.
+    int sym, nH, nHpad;
+    const double *tab_sym;
     // Regular term structures (afiv_price.hip, NFAC): step_count = 0 (none), 1 (successive year
     // fractions are step_dt[0] apart) or 2 (step_dt[0] plus k times step_dt[1] = one day, k <= 3 in
     // bits 2t, 2t+1 of step_sel for the step from maturity t-1 to t).

@@ -187,15 +187,27 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
 // -- so exp(-d T_t) = exp(-d T_{t-1}) exp(-d base/365) exp(-d/365)^k costs 1 + k complex
 // multiplications per maturity; the thread keeps the two factors.  Some 40 multiplications add
 // rounding of a few eps to a factor that is evaluated to 2 ulp otherwise.
-template <int NCTP, int NFAC>
+//
+// SYM: the strikes are symmetric about the forward-free money line (log K_k = -log K_{nK-1-k}, as
+// in linspace(-a, a, n)), so cos(x log K) is shared and sin(x log K) only changes sign between a
+// strike and its mirror image: with C_j = sum_n [E sin alpha] cos(x_n log K), S_j = sum_n
+// [E cos alpha] sin(x_n log K), the integral is C_j - S_j at a strike and C_j + S_j at its mirror.
+// The contraction then runs over half the strikes: four [16 x 144] x [144 x nH] products (C_1, C_2,
+// S_1, S_2; NCTP column tiles each) instead of one [16 x 576] x [576 x nK] -- half the matrix work.
+// The operand block is stored as four planes (E sin alpha | E cos alpha) x (j = 1 | 2) of 144
+// columns; the strike multiplier K_k of the second integral is applied when the tiles are combined.
+template <int NCTP, int NFAC, bool SYM>
 __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double *__restrict__ params,
                                                         int64_t N, double *__restrict__ ratio_out)
 {
-    constexpr int KS = WAVES / NCTP;          // K ranges
-    constexpr int KLEN = KDIM / KS;           // contraction indices per wave
-    constexpr int NKP = 16 * NCTP;            // padded strike count used for the partial tiles
+    // general: WAVES = NCTP column tiles x KS ranges of the 576-long contraction
+    // SYM:     WAVES = 4 planes x NCTP column tiles x KS ranges of a plane's 144 columns
+    constexpr int KS = SYM ? WAVES / (4 * NCTP) : WAVES / NCTP;
+    constexpr int KLEN = (SYM ? NQ : KDIM) / KS;   // contraction indices per wave
+    constexpr int NKP = 16 * NCTP;            // padded (half-)strike count used for the partial tiles
+    static_assert(KS >= 1 && KS * (SYM ? 4 * NCTP : NCTP) == WAVES, "waves split evenly");
     static_assert(KLEN % 4 == 0, "K range must be a multiple of the MFMA depth");
-    static_assert(KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
+    static_assert((SYM ? 4 : 1) * KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
 
     __shared__ double lds[2 * XBUF];
     const int tid = threadIdx.x;
@@ -205,12 +217,15 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     const int n = tid - sl * NQ;
     const double phi = c_lag_x[n];
     const double wp = c_lag_wp[n];
-    const int ct = wave % NCTP, kq = wave / NCTP;
+    // general: (column tile, K range).  SYM: (plane = wave & 3, column tile, K range of the plane)
+    const int plane = wave & 3;
+    const int ct = SYM ? (wave >> 2) % NCTP : wave % NCTP;
+    const int kq = SYM ? (wave >> 2) / NCTP : wave / NCTP;
     // waves w, w+4, ... share a SIMD: each issues its MFMA chain after a different one of the
     // step's 2*MT characteristic-function evaluations
     const int my_slot = (wave >> 2) * (NEVAL / (WAVES / 4));
     static_assert(NEVAL >= WAVES / 4, "one distinct MFMA slot per wave of a SIMD");
-    const int nT = g.nT, nK = g.nK, nKpad = g.nKpad;
+    const int nT = g.nT, nK = g.nK, nKpad = SYM ? g.nHpad : g.nKpad;   // nKpad: table row length
     const bool ct_live = 16 * ct < nKpad;
     const int ntiles = (nT + MT - 1) / MT;
     const int64_t nchunks = (N + SPB - 1) / SPB;
@@ -264,13 +279,17 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             constexpr int NB = pick_batch(NSTEP);                  // table loads in flight per batch
             constexpr int NPAIR = NSTEP / (2 * NB);                // 0: a single batch
             static_assert(NB * (NPAIR ? 2 * NPAIR : 1) == NSTEP, "one batch or pairs of batches");
-            const double *xa = xr + (lane & 15) * XSTRIDE + kq * KLEN + (lane >> 4);
+            const int kfirst = (SYM ? plane * NQ : 0) + kq * KLEN;          // first operand column of this wave
+            const double *xa = xr + (lane & 15) * XSTRIDE + kfirst + (lane >> 4);
             // Table fragments through a buffer resource: one 32-bit per-lane offset plus a
             // scalar offset per load (plain pointers cost a 64-bit address register pair per
             // load here).  Reads past the table return 0.
+            // SYM: table rows are [cos | sin][144]; planes 0, 1 (E sin alpha) take cos, planes 2, 3 sin
+            const int tfirst = SYM ? (plane >> 1) * NQ + kq * KLEN : kfirst;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<double *>(g.tab), 0, KDIM * nKpad * (int)sizeof(double), 0x00020000);
-            const unsigned lo = (unsigned)(((kq * KLEN + (lane >> 4)) * nKpad + 16 * ct + (lane & 15)) * 8);
+                const_cast<double *>(SYM ? g.tab_sym : g.tab), 0, (SYM ? 2 * NQ : KDIM) * nKpad * (int)sizeof(double),
+                0x00020000);
+            const unsigned lo = (unsigned)(((tfirst + (lane >> 4)) * nKpad + 16 * ct + (lane & 15)) * 8);
             const unsigned kstride = (unsigned)(4 * nKpad * 8);     // bytes per MFMA k-step
             double b0[NB], b1[NB];
 #pragma unroll
@@ -318,8 +337,14 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     }
                     x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq, ex0);
                 }
-                if (sl < SPB)     // spare lanes of the last wave own no row
-                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * n]) = x0;
+                if (sl < SPB) {   // spare lanes of the last wave own no row
+                    if (SYM) {
+                        xw[(sl * MT + tl) * XSTRIDE + 0 * NQ + n] = x0.x;
+                        xw[(sl * MT + tl) * XSTRIDE + 2 * NQ + n] = x0.y;
+                    } else {
+                        *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * n]) = x0;
+                    }
+                }
             }
             if (do_mfma && 2 * tl == my_slot) mfma_chain();
             if (have_cur) {
@@ -332,20 +357,56 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     }
                     x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr, ex1);
                 }
-                if (sl < SPB)
-                    *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * (NQ + n)]) = x1;
+                if (sl < SPB) {
+                    if (SYM) {
+                        xw[(sl * MT + tl) * XSTRIDE + 1 * NQ + n] = x1.x;
+                        xw[(sl * MT + tl) * XSTRIDE + 3 * NQ + n] = x1.y;
+                    } else {
+                        *reinterpret_cast<double2 *>(&xw[(sl * MT + tl) * XSTRIDE + 2 * (NQ + n)]) = x1;
+                    }
+                }
             }
             if (do_mfma && 2 * tl + 1 == my_slot) mfma_chain();
         }
         __syncthreads();          // operand block G complete; every MFMA chain of step G-1 done
         if (have_prev && ct_live) {
             // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
-            double *pw = xr + (kq * ROWS) * NKP + 16 * ct + (lane & 15);
+            double *pw = xr + (((SYM ? plane * KS : 0) + kq) * ROWS) * NKP + 16 * ct + (lane & 15);
 #pragma unroll
             for (int i = 0; i < 4; ++i) pw[((lane >> 4) + 4 * i) * NKP] = acc[i];
         }
         __syncthreads();
-        for (int o = tid; have_prev && o < ROWS * NKP; o += THREADS) {
+        if (SYM) {
+            // item = (row, half-strike k, direct | mirror image)
+            for (int o = tid; have_prev && o < ROWS * NKP * 2; o += THREADS) {
+                const int row = o / (2 * NKP);
+                const int rem = o - row * (2 * NKP);
+                const int k = rem >> 1;
+                const bool mirror = rem & 1;
+                const int col = mirror ? nK - 1 - k : k;
+                const int rs = row / MT;
+                const int t = prev_tile * MT + (row - rs * MT);
+                const int64_t s = prev_chunk * SPB + rs;
+                if (rs < SPB && s < N && t < nT && k < g.nH && (!mirror || col != k)) {
+                    double v[4];
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int q = 0; q < KS; ++q) sum += xr[((pl * KS + q) * ROWS + row) * NKP + k];
+                        v[pl] = sum;
+                    }
+                    // planes: 0 = C_1, 1 = C_2, 2 = S_1, 3 = S_2
+                    const double p1 = mirror ? v[0] + v[2] : v[0] - v[2];
+                    const double p2 = mirror ? v[1] + v[3] : v[1] - v[3];
+                    const double Dq = g.Dq[t], Dr = g.Dr[t], K = g.Kmult[col];
+                    double call = (0.5 * Dq - 0.5 * (K * Dr)) + (p1 - K * p2);
+                    if (!(g.term[t] > 0.0)) call = 0.0;          // expired option: NPV 0
+                    ratio_out[(s * nT + t) * (int64_t)nK + col] = call / g.disc_tau[t];
+                }
+            }
+        }
+        for (int o = tid; !SYM && have_prev && o < ROWS * NKP; o += THREADS) {
             const int row = o / NKP;
             const int col = o - row * NKP;
             const int rs = row / MT;
@@ -407,16 +468,20 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     // one workgroup per CU is resident (LDS); a few waves of workgroups per CU balance the tail
     const int64_t blocks = chunks < 256 * 8 ? chunks : 256 * 8;
     dim3 grid((unsigned)blocks), block(THREADS);
-#define AFIV_LAUNCH_PRICE(NCT, NF) hipLaunchKernelGGL((price_kernel<NCT, NF>), grid, block, 0, s, g, params, N, ratio_out)
-#define AFIV_LAUNCH_PRICE_NF(NCT)                        \
-    do {                                                 \
-        if (g.step_count == 1) AFIV_LAUNCH_PRICE(NCT, 1); \
-        else if (g.step_count == 2) AFIV_LAUNCH_PRICE(NCT, 2); \
-        else AFIV_LAUNCH_PRICE(NCT, 0);                  \
+#define AFIV_LAUNCH_PRICE(NCT, NF, SY) \
+    hipLaunchKernelGGL((price_kernel<NCT, NF, SY>), grid, block, 0, s, g, params, N, ratio_out)
+#define AFIV_LAUNCH_PRICE_NF(NCT, SY)                        \
+    do {                                                     \
+        if (g.step_count == 1) AFIV_LAUNCH_PRICE(NCT, 1, SY); \
+        else if (g.step_count == 2) AFIV_LAUNCH_PRICE(NCT, 2, SY); \
+        else AFIV_LAUNCH_PRICE(NCT, 0, SY);                  \
     } while (0)
-    if (nct == 1) AFIV_LAUNCH_PRICE_NF(1);
-    else if (nct == 2) AFIV_LAUNCH_PRICE_NF(2);
-    else AFIV_LAUNCH_PRICE_NF(4);
+    if (g.sym) {
+        if (g.nHpad == 16) AFIV_LAUNCH_PRICE_NF(1, true);
+        else AFIV_LAUNCH_PRICE_NF(2, true);
+    } else if (nct == 1) AFIV_LAUNCH_PRICE_NF(1, false);
+    else if (nct == 2) AFIV_LAUNCH_PRICE_NF(2, false);
+    else AFIV_LAUNCH_PRICE_NF(4, false);
 #undef AFIV_LAUNCH_PRICE_NF
 #undef AFIV_LAUNCH_PRICE
     return hipGetLastError() == hipSuccess ? 0 : -3;
