@@ -443,3 +443,38 @@ def test_wave_per_surface_mode_equals_workgroup_per_surface_mode(afiv, grid821, 
     assert torch.equal(torch.nan_to_num(iv_big, nan=-1.0), torch.nan_to_num(iv_small, nan=-1.0))
     assert torch.equal(fl_big, fl_small)
     assert bool(torch.isnan(iv_big[11]).all())
+
+
+@pytest.mark.parametrize("logm", [
+    np.linspace(-0.3, 0.1, 7),            # asymmetric: general contraction, one column tile
+    np.linspace(-0.25, 0.15, 21),         # asymmetric, two column tiles
+    np.linspace(-0.2, 0.3, 50),           # asymmetric, four column tiles
+    np.linspace(-0.2, 0.2, 4),            # symmetric, smallest grid that takes the half-strike path
+    np.linspace(-0.2, 0.2, 5),            # symmetric, odd (the middle strike is its own mirror image)
+    np.linspace(-0.2, 0.2, 33),           # symmetric, 17 half-strikes: two column tiles
+    np.linspace(-0.3, 0.3, 64),           # symmetric, largest
+], ids=["asym7", "asym21", "asym50", "sym4", "sym5", "sym33", "sym64"])
+def test_price_symmetric_and_asymmetric_strike_grids(afiv, logm):
+    tau = np.array([0.05, 0.3, 1.0, 2.5])
+    grid = afiv.Grid(logm, tau, R, Q)
+    p = sample_params(80, 51)
+    got = grid.price(dev(p)).cpu().numpy()
+    ref = oracle.price_ratio_grid(p, logm, tau, R, Q)
+    err = np.abs(got - ref) / price_tol(ref, p)
+    assert np.all(err <= 1.0), f"max excess {err.max():.3g}"
+    big = p[:, 2] >= 0.06
+    assert np.all(np.abs(got - ref)[big] <= price_tol(ref[big]))
+
+
+def test_half_strike_contraction_agrees_with_general_contraction(afiv):
+    """A symmetric grid and the same grid with one strike moved by 1e-13 (which sends it down the
+    general path) price every other strike identically to rounding."""
+    logm = np.linspace(-0.2, 0.2, 21)
+    moved = logm.copy()
+    moved[3] += 1e-13
+    tau = np.array([0.1, 0.5, 1.0, 2.0])
+    p = dev(sample_params(64, 52))
+    a = afiv.Grid(logm, tau, R, Q).price(p).cpu().numpy()
+    b = afiv.Grid(moved, tau, R, Q).price(p).cpu().numpy()
+    keep = np.arange(21) != 3
+    assert np.abs(a[:, :, keep] - b[:, :, keep]).max() <= 1e-14
