@@ -21,7 +21,7 @@
  *
  * Parity pin: the price restatement reproduces the QuantLib-evaluated calibration objective
  * values stored by the reference (NIFTY_heston_single_params.pickle, field fit_errors); see
- * tests/test_oracle_pin.py.  Point-wise QuantLib prices are not stored anywhere in the
+ * tests/test_oracle.py.  Point-wise QuantLib prices are not stored anywhere in the
  * reference, so that aggregate is the only full-precision pin.
  */
 #include <complex.h>
