@@ -1,6 +1,7 @@
 // Host side of libafiv.so: the extern "C" entry points declared in include/afiv.h.
 // Creation calls allocate and fill device memory; execution calls only validate their
 // arguments and enqueue kernels on the caller's stream.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -63,7 +64,8 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
         if (!(std::fabs(logm[k] + logm[nK - 1 - k]) <= 8.9e-16 * scale)) sym = false;
     const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
     const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
-    const size_t nd = n_const + n_point;
+    const size_t n_order = ((size_t)nT * nK * sizeof(unsigned short) + 31) / 32 * 4;   // in doubles, 32-byte multiple
+    const size_t nd = n_const + n_point + n_order;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
            *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
@@ -113,6 +115,21 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
         }
     }
 
+    {
+        // service order of the implied-vol kernel's queue
+        const int per = nT * nK;
+        std::vector<double> score(per);
+        std::vector<unsigned short> idx(per);
+        for (int t = 0; t < nT; ++t)
+            for (int k = 0; k < nK; ++k) {
+                score[t * nK + k] = tau[t] > 0.0 ? std::fabs((r - q) * tau[t] - logm[k]) / std::sqrt(tau[t]) : 0.0;
+                idx[t * nK + k] = (unsigned short)(t * nK + k);
+            }
+        std::stable_sort(idx.begin(), idx.end(),
+                         [&](unsigned short a, unsigned short b) { return score[a] > score[b]; });
+        std::memcpy(h.data() + n_const + n_point, idx.data(), per * sizeof(unsigned short));
+    }
+
     afiv_grid *g = new (std::nothrow) afiv_grid();
     if (!g) return AFIV_E_HIP;
     if (hipGetDevice(&g->device) != hipSuccess) { delete g; return AFIV_E_HIP; }
@@ -141,6 +158,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     v.nHpad = nHpad;
     v.tab_sym = v.tab + (size_t)AFIV_KDIM * nKpad;
     v.point = dev + n_const;
+    v.order = reinterpret_cast<const unsigned short *>(dev + n_const + n_point);
     // whole-day year fractions with at most two distinct increments: see price_kernel's NFAC
     v.step_count = 0;
     v.step_dt[0] = v.step_dt[1] = 0.0;

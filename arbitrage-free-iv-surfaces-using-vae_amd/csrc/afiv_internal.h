@@ -35,6 +35,10 @@ struct GridView {
     int step_count;
     double step_dt[2];
     unsigned long long step_sel;
+    const unsigned short *order;   // [nT*nK] lattice points by decreasing |log(F/K)|/sqrt(tau): the order
+                                   // in which the implied-vol kernel hands points to lanes (points far
+                                   // from the money need the most root-finder iterations; served first,
+                                   // they leave a short tail)
     double *point;            // [nT*nK][4] per-call table of the implied-vol kernel (log F/K and the
                               // Black-Scholes values at the bracket ends for the call's spot);
                               // rewritten by every implied-vol call, so calls on one grid must

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
     double *strike = reinterpret_cast<double *>(mat + AFIV_MAX_MATURITIES);   // [64]
     double *logm = strike + AFIV_MAX_STRIKES;            // [64]
     double *price_all = logm + AFIV_MAX_STRIKES;         // [NG][per]
+    unsigned short *order = reinterpret_cast<unsigned short *>(price_all + (size_t)NG * per);   // [per] queue position -> lattice point
     __shared__ int skip_all[NG][AFIV_MAX_MATURITIES];
     __shared__ int ctr_all[NG][8];                       // queue head, nan, bad, static, calendar, butterfly
     const int tid = threadIdx.x, lane = tid & 63, gid = tid / GT, lt = tid % GT;
@@ -397,9 +398,10 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
         strike[k] = spot * g.Kmult[k];
         logm[k] = g.logm[k];
     }
+    for (int i = tid; i < per; i += THREADS) order[i] = g.order[i];
     __syncthreads();
 
-    const float inv_nT = 1.0f / (float)nT, inv_nK = 1.0f / (float)nK;
+    const float inv_nK = 1.0f / (float)nK;
     const double nan = __builtin_nan("");
     const double rq = g.r - g.q;
     const afivm::ExpCoef ec = afivm::load_exp_coef();
@@ -475,8 +477,8 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                     if (j >= per) {
                         exhausted = true;
                     } else {
-                        const int k = small_div(j, inv_nT), t = j - __mul24(k, nT);
-                        i_cur = __mul24(t, nK) + k;
+                        i_cur = order[j];
+                        const int t = small_div(i_cur, inv_nK), k = i_cur - __mul24(t, nK);
                         const PointRow pt = point[i_cur];
                         const MatRow m = mat[t];
                         c.tau = m.tau;
@@ -733,7 +735,8 @@ namespace {
 size_t surface_lds_bytes(const GridView &g, int groups)
 {
     return sizeof(double) * ((size_t)ERFCX_LDS + 5 * AFIV_MAX_MATURITIES + 2 * AFIV_MAX_STRIKES +
-                             (size_t)groups * g.nT * g.nK);
+                             (size_t)groups * g.nT * g.nK) +
+           ((size_t)g.nT * g.nK * sizeof(unsigned short) + 7) / 8 * 8;
 }
 
 template <int VARIANT, bool CHECKS, int GT, int THREADS>
