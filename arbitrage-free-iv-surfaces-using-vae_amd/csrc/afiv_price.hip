@@ -94,8 +94,9 @@ __device__ __forceinline__ double ldtab(__amdgpu_buffer_rsrc_t rs, unsigned voff
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
 
-// Maturity-independent part of A_j(phi) for one integral.
-struct JState { Cx d, a, p, inv1mp; };
+// Maturity-independent part of A_j(phi) for one integral: d, a = t1 - d, sum = t1 + d and
+// pq = p / (1 - p) with p = a / sum (the series branch for tiny vol-of-vol keeps p itself in pq).
+struct JState { Cx d, a, pq, sum; };
 
 struct Model { double sigma2, c1, c2; bool main_branch; };
 
@@ -117,23 +118,22 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
     s.d = csqrt_principal(zz);
     if (m.main_branch) {
         const Cx su = {m.sigma2 * phi * u.r, m.sigma2 * phi * u.i};       // sigma^2 phi u
-        Cx sum;
         if (t1.r >= 0.0) {
-            sum = {t1.r + s.d.r, t1.i + s.d.i};
-            s.a = cmul(su, crcp(sum));
+            s.sum = {t1.r + s.d.r, t1.i + s.d.i};
+            s.a = cmul(su, crcp(s.sum));
         } else {
             s.a = {t1.r - s.d.r, t1.i - s.d.i};
-            sum = cmul(su, crcp(s.a));
+            s.sum = cmul(su, crcp(s.a));
         }
-        s.p = cmul(s.a, crcp(sum));
-        s.inv1mp = crcp(Cx{1.0 - s.p.r, -s.p.i});
+        const Cx p = cmul(s.a, crcp(s.sum));
+        s.pq = cmul(p, crcp(Cx{1.0 - p.r, -p.i}));
     } else {
         // vol-of-vol <= 1e-5 series, as the reference engine switches: td = phi/(2 t1) u ;
         // p = td sigma^2/(t1+d)
         const Cx h = crcp(Cx{2.0 * t1.r, 2.0 * t1.i});
         s.a = cmul(Cx{phi * h.r, phi * h.i}, u);
-        s.p = cmul(Cx{s.a.r * m.sigma2, s.a.i * m.sigma2}, crcp(Cx{t1.r + s.d.r, t1.i + s.d.i}));
-        s.inv1mp = {0.0, 0.0};
+        s.sum = {t1.r + s.d.r, t1.i + s.d.i};
+        s.pq = cmul(Cx{s.a.r * m.sigma2, s.a.i * m.sigma2}, crcp(s.sum));
     }
     return s;
 }
@@ -153,20 +153,25 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
                                            double T, double ddt, double disc, Cx ex)
 {
     const Cx omex = {1.0 - ex.r, -ex.i};             // 1 - ex
-    const Cx pe = cmul(s.p, ex);
-    const Cx num = {1.0 - pe.r, -pe.i};              // 1 - p ex
-    const Cx f1 = cmul(cmul(s.a, omex), crcp(num));
     Cx A;
     if (m.main_branch) {
-        // g = log((1 - p ex)/(1 - p)) = log(1 + w1) with w1 = p (1 - ex)/(1 - p) formed directly,
-        // so that the logarithm keeps its relative accuracy when w1 ~ sigma^2
-        const Cx w1 = cmul(cmul(s.p, omex), s.inv1mp);
-        const double glr = 0.5 * afivm::log1p_f64(__builtin_fma(w1.r, w1.r, __builtin_fma(w1.i, w1.i, 2.0 * w1.r)));
-        const double gli = afivm::atan2_f64(w1.i, 1.0 + w1.r);
+        // w1 = p (1 - ex)/(1 - p), so that (1 - p ex)/(1 - p) = 1 + w1: the logarithm g = log(1 + w1)
+        // keeps its relative accuracy when w1 ~ sigma^2, and the first term of A,
+        // a (1 - ex)/(1 - p ex), equals (t1 + d) w1/(1 + w1) -- one complex reciprocal serves both
+        const Cx w1 = cmul(s.pq, omex);
+        const double q = __builtin_fma(w1.r, w1.r, __builtin_fma(w1.i, w1.i, 2.0 * w1.r));   // |1 + w1|^2 - 1
+        const double zr = 1.0 + w1.r;
+        const double inv = afivm::rcp_f64(1.0 + q);
+        const Cx wz = cmul(w1, Cx{zr * inv, -w1.i * inv});                                    // w1 / (1 + w1)
+        const Cx f1 = cmul(s.sum, wz);
+        const double glr = 0.5 * afivm::log1p_f64(q);
+        const double gli = afivm::atan2_f64(w1.i, zr);
         A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
     } else {
-        const Cx gl = cmul(s.p, omex);               // g = p (1 - ex)
+        const Cx pe = cmul(s.pq, ex);
+        const Cx f1 = cmul(cmul(s.a, omex), crcp(Cx{1.0 - pe.r, -pe.i}));
+        const Cx gl = cmul(s.pq, omex);              // g = p (1 - ex)
         A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * gl.r / m.sigma2);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gl.i / m.sigma2);
     }
