@@ -193,7 +193,7 @@ __device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, d
 // One workgroup per surface.
 constexpr int ARB_THREADS = 256;
 #ifndef AFIV_IV_REFILL_LANES
-#define AFIV_IV_REFILL_LANES 6            // idle lanes of a wave that trigger a refill
+#define AFIV_IV_REFILL_LANES 8            // idle lanes of a wave that trigger a refill
 #endif
 #ifndef AFIV_IV_THREADS
 #define AFIV_IV_THREADS 512               // fused kernel, wave-per-surface mode: 8 surfaces in flight per workgroup
