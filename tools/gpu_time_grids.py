@@ -29,3 +29,10 @@ for name, (logm, tau, n) in grids.items():
     pts = len(logm) * len(tau)
     print(f"{name}: price {tp:.2f} ms ({tp*1e6/n/len(tau):.1f} ns per maturity), iv+checks {ti:.2f} ms "
           f"({ti*1e6/n/pts:.2f} ns per point), {n/(tp+ti)*1e3/1e6:.2f} M surfaces/s", flush=True)
+
+# small batches on the reference's lattice: latency of the whole path (one afiv_surface call)
+g = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
+for n in (1, 100, 1000, 10000):
+    p = dev(sample_params(n, 5))
+    t = timeit(lambda: g.surface(p, SPOT, "A"), n=20)
+    print(f"8x21, N={n}: {t*1e3:.0f} us per call ({n/t*1e3:.0f} surfaces/s)", flush=True)
