@@ -534,11 +534,15 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 const bool interp = fabs(spre) > delta && fabs(fcur) < fabs(fpre);
                 const bool sec = xpre == xblk;
                 const double a = fpre - fcur, b = xpre - xcur;
-                // secant: -fcur (xcur - xpre) / (fcur - fpre) = -((fcur b) / a); otherwise dpre = a / b
-                const double q = fdivq(sec ? fcur * b : a, sec ? a : b);
-                const double dblk = fdivq(fblk - fcur, xblk - xcur);
-                const double q3 = fdivq(-fcur * (fblk * dblk - fpre * q), dblk * q * (fblk - fpre));
-                const double stry = sec ? -q : q3;
+                // secant:  -fcur (xcur - xpre) / (fcur - fpre) = (-fcur b) / a.
+                // inverse quadratic, brentq.c's -fcur (fblk dblk - fpre dpre) / (dblk dpre (fblk - fpre))
+                // with dpre = a / b, dblk = A / B multiplied through by b B: one quotient instead
+                // of three, -fcur (fblk A b - fpre a B) / (A a (fblk - fpre)); the same step to a
+                // few ulp (the iteration paths stay those of the oracle, see the tests).
+                const double A = fblk - fcur, B = xblk - xcur;
+                const double num_q = -fcur * (fblk * A * b - fpre * a * B);
+                const double den_q = A * a * (fblk - fpre);
+                const double stry = fdivq(sec ? -fcur * b : num_q, sec ? a : den_q);
                 const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
                 const bool take = interp && 2 * fabs(stry) < lim;
                 spre = take ? scur : sbis;
