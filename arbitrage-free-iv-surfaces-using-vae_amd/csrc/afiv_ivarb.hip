@@ -149,6 +149,9 @@ __device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, cons
     const double h1 = e * p1, h2 = (e * c.ratio) * p2;
     const double n1 = x1 > 0 ? 1.0 - h1 : h1;
     const double n2 = x2 > 0 ? 1.0 - h2 : h2;
+    // The two products are rounded separately, as NumPy rounds them (this unit is compiled without
+    // FMA contraction): deep in the money the option's time value is a 1e-10 remainder of that
+    // difference, and a fused multiply-add there moves the root by up to 1e-2 in vol.
     if (VARIANT == AFIV_VARIANT_A) return c.disc * (c.F * n1 - c.K * n2);
     return c.sdq * n1 - c.kdr * n2;
 }
