@@ -89,10 +89,9 @@ __device__ __forceinline__ double fdivq(double n, double d)
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-// Segment and local coordinate of erfcx's table for u >= 0 (see ndtr_dev).
-__device__ __forceinline__ const d2v *erfcx_row(double u, const double *__restrict__ tab, double *f)
+// Segment and local coordinate of erfcx's table for t = 64/(1 + u) (see ndtr_dev).
+__device__ __forceinline__ const d2v *erfcx_row(double t, const double *__restrict__ tab, double *f)
 {
-    const double t = 64.0 * afivm::rcp_f64(1.0 + u);
     const int seg = (int)fmin(t, 63.0);
     *f = (t - (double)seg) - 0.5;
     // 24-bit multiply: full rate, where a 32-bit v_mul_lo_u32 runs at a quarter of it
@@ -132,9 +131,12 @@ __device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, cons
     const double d2 = d1 - den;
     const double x1 = d1 * sqrth, x2 = d2 * sqrth;
     const double u1 = fabs(x1), u2 = fabs(x2);
+    // both table coordinates from one reciprocal: 64/(1+u1) = 64 (1+u2) / ((1+u1)(1+u2))
+    const double w1 = 1.0 + u1, w2 = 1.0 + u2;
+    const double r64 = 64.0 * afivm::rcp_f64(w1 * w2);
     double f1, f2;
-    const d2v *r1 = erfcx_row(u1, tab, &f1);
-    const d2v *r2 = erfcx_row(u2, tab, &f2);
+    const d2v *r1 = erfcx_row(r64 * w2, tab, &f1);
+    const d2v *r2 = erfcx_row(r64 * w1, tab, &f2);
     const d2v a0 = r1[0], a1 = r1[1], a2 = r1[2], a3 = r1[3];
     const double a4 = reinterpret_cast<const double *>(r1)[8];
     const d2v b0 = r2[0], b1 = r2[1], b2 = r2[2], b3 = r2[3];
