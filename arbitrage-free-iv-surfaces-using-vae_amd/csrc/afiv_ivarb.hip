@@ -523,7 +523,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                                 xcur = sw ? xa : xb;  fcur = sw ? fa : fb;
                                 xblk = xpre;          fblk = fpre;
                                 spre = scur = xb - xa;
-                                delta = (xtol + rtol * fabs(xcur)) / 2;
+                                delta = __builtin_fma(0.5 * rtol, fabs(xcur), 0.5 * xtol);   // (xtol + rtol |xcur|)/2 in one operation
                                 sbis = (xblk - xcur) / 2;
                                 iter = 0;
                                 phase = PH_ITER;         // |sbis| = 1.4995 > delta: never done here
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 const double num_q = -fcur * (fblk * A * b - fpre * a * B);
                 const double den_q = A * a * (fblk - fpre);
                 const double stry = fdivq(sec ? -fcur * b : num_q, sec ? a : den_q);
-                const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
+                const double lim = fmin(fabs(spre), __builtin_fma(3.0, fabs(sbis), -delta));
                 const bool take = interp && 2 * fabs(stry) < lim;
                 spre = take ? scur : sbis;
                 scur = take ? stry : sbis;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                 fpre = sw ? fc : fpre;
                 fcur = sw ? fblk : fc;
                 fblk = sw ? fc : fblk;
-                delta = (xtol + rtol * fabs(xcur)) / 2;
+                delta = __builtin_fma(0.5 * rtol, fabs(xcur), 0.5 * xtol);   // (xtol + rtol |xcur|)/2 in one operation
                 sbis = (xblk - xcur) / 2;
                 const bool failed = isnan(f) || iter == BRENT_MAXITER;
                 const bool done = fcur == 0 || fabs(sbis) < delta;
