@@ -43,8 +43,14 @@ def pricing_flops(n_t: int, n_k: int) -> float:
     return n_t * 288 * 400.0 + n_t * n_k * 288 * 4.0
 
 
+def iv_checks_flops(n_t: int, n_k: int) -> float:
+    """Algorithmic FLOPs of the implied-vol + checks kernel per surface: 12 root-finder iterations
+    x 120 per point, plus 125 per point for the three checks."""
+    return n_t * n_k * (1440.0 + 125.0)
+
+
 def surface_flops(n_t: int, n_k: int) -> float:
-    return pricing_flops(n_t, n_k) + n_t * n_k * (1440.0 + 125.0)
+    return pricing_flops(n_t, n_k) + iv_checks_flops(n_t, n_k)
 
 
 def synthetic_params(n: int, seed: int, device) -> torch.Tensor:
@@ -193,13 +199,14 @@ def main():
         value = total_surfaces / elapsed
         achieved = pricing_flops(N_MATURITIES, N_STRIKES) * n_local / k_price / 1e12
         fl = flags.cpu().numpy()
-        traffic = None
+        traffic = traffic_iv = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
             if pmc.get("surfaces_per_launch") == n_local:
                 traffic = pmc.get("price_kernel_hbm_bytes_per_launch")
+                traffic_iv = pmc.get("surface_kernel_hbm_bytes_per_launch")
         out = {
             "metric": "arb-checked IV surfaces/sec", "value": value, "unit": "surfaces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,6 +224,15 @@ def main():
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_surface": pricing_flops(N_MATURITIES, N_STRIKES),
                          "kernel_ms": {"price": k_price * 1e3, "implied_vol_and_checks": k_iv * 1e3}},
+            # the other kernel of a step, same conventions (it is the longer of the two by a little)
+            "roofline_iv_checks": {"bound": "mfma", "pipe": "FP64 vector (no matrix work in this kernel)",
+                                   "kernel": "surface_kernel",
+                                   "achieved": iv_checks_flops(N_MATURITIES, N_STRIKES) * n_local / k_iv / 1e12,
+                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": iv_checks_flops(N_MATURITIES, N_STRIKES) * n_local / k_iv / 1e12
+                                   / FP64_VECTOR_PEAK_TFLOPS,
+                                   "traffic": traffic_iv,
+                                   "flops_per_surface": iv_checks_flops(N_MATURITIES, N_STRIKES)},
             "whole_path_tflops": surface_flops(N_MATURITIES, N_STRIKES) * value / 1e12,
             "check": {"valid_surfaces_frac": float(np.mean((fl[:, 3] & 4) != 0)),
                       "arbitrage_free_frac": float(np.mean((fl[:, 3] & 1) != 0)),
