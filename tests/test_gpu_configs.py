@@ -322,3 +322,40 @@ def test_config4_stage2_density_wasserstein(afiv, golden_dir):
             fin = dist[c, d][np.isfinite(dist[c, d])]
             want = 1e10 if base_h[c, d] >= 1e10 else base_h[c, d] + float(pin["wasserstein_weight"]) * (fin.mean() if fin.size else 0.0)
             assert abs(total[c, d] - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_config3_full_size_one_million_surfaces(afiv):
+    """BASELINE configs[2] at its full size on one GPU (1 048 576 surfaces x 20 x 50: 8.4 GB of
+    ratios, 8.4 GB of vols): 64-bit indexing, and the size-independent properties -- a slice of the
+    big batch equals the same surfaces run as a small batch, bit for bit; oracle on a few rows."""
+    logm = np.linspace(-0.2, 0.2, 50)
+    tau = np.round(np.linspace(30, 730, 20)) / 365.0
+    n = 1 << 20
+    free, _total = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip("needs 24 GB of free device memory")
+    grid = afiv.Grid(logm, tau, R, Q)
+    base = sample_params(4096, 3)
+    params = dev(np.tile(base, (n // 4096, 1)))
+    params[-1] = torch.tensor([2.0, 0.09, 0.3, -0.7, 0.09], dtype=torch.float64)     # the very last row is its own
+    ratio = grid.price(params)
+    iv, flags = grid.implied_vol_checked(ratio, SPOT, "A")
+    torch.cuda.synchronize()
+    # tiled input: every block of 4096 surfaces repeats the first one (but for the last row)
+    for blk in (1, 97, 255):
+        a, b = blk * 4096, (blk + 1) * 4096 - (1 if blk == 255 else 0)
+        assert torch.equal(torch.nan_to_num(iv[a:b], nan=-1.0), torch.nan_to_num(iv[:b - a], nan=-1.0))
+        assert torch.equal(flags[a:b], flags[:b - a])
+        assert torch.equal(torch.nan_to_num(ratio[a:b], nan=-1.0), torch.nan_to_num(ratio[:b - a], nan=-1.0))
+    tail = slice(n - 3, n)
+    iv_t, fl_t = grid.implied_vol_checked(ratio[tail].contiguous(), SPOT, "A")
+    assert torch.equal(torch.nan_to_num(iv[tail], nan=-1.0), torch.nan_to_num(iv_t, nan=-1.0))
+    assert torch.equal(flags[tail], fl_t)
+    p = params[tail].cpu().numpy()
+    ref = oracle.price_ratio_grid(p, logm, tau, R, Q)
+    got = ratio[tail].cpu().numpy()
+    assert np.all(np.abs(got - ref) <= price_tol(ref, p))
+    assert np.array_equal(flags[tail].cpu().numpy(),
+                          oracle.arb_check(iv[tail].cpu().numpy(), got, logm, tau, SPOT, R, Q, "A"))
+    del ratio, iv, flags
+    torch.cuda.empty_cache()
