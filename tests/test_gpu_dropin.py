@@ -147,6 +147,21 @@ def test_generate_iv_surface_signature_and_values(mods):
     assert np.array_equal(np.nan_to_num(ivs[3], nan=-1), np.nan_to_num(iv, nan=-1))
 
 
+def test_older_twin_module_resolves_to_same_function(mods):
+    """generate_surface_for_date.generate_iv_surface (reference :462-504) is the same computation
+    as generate_iv_surface_by_date's (:267-322): one implementation under both names."""
+    twin = importlib.import_module("generate_surface_for_date")
+    assert twin.generate_iv_surface is mods["generate_iv_surface_by_date"].generate_iv_surface
+    np.testing.assert_array_equal(twin.T_grid, T_GRID)
+    np.testing.assert_array_equal(twin.logm_grid, LOGM_GRID)
+    params = np.array([2.0, 0.04, 0.3, -0.7, 0.04])
+    iv, ok = twin.generate_iv_surface(params, twin.T_grid, twin.logm_grid, 100.0, 0.067, 0.0)
+    ratio = oracle.price_ratio_grid(params[None], LOGM_GRID, T_GRID)
+    ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, 100.0, 0.067, 0.0, "A")[0]
+    assert ok and iv.shape == (8, 21)
+    np.testing.assert_allclose(iv, ref, atol=1e-6, rtol=0, equal_nan=True)
+
+
 def test_cli_offline_run_writes_reference_outputs(mods, golden_dir, tmp_path, capsys):
     G = mods["generate_iv_surface_by_date"]
     d = np.load(f"{golden_dir}/decoder.npz")
