@@ -1,0 +1,91 @@
+"""Random lattices and parameter rows for the parity sweep (tests/test_gpu_random_lattices.py,
+tools/gpu_fuzz.py): 1..64 strikes and maturities, symmetric / asymmetric / unsorted / repeated
+strikes, whole-day / irregular / unsorted / sub-day maturities, day truncation on and off, rates
+of either sign, spots over five decades, both Black-Scholes forms, ragged batch sizes,
+benchmark-sampler parameters mixed with corner values.  ``run_case`` compares one trial with the
+CPU oracle by the rules of tests/test_gpu_parity.py."""
+import numpy as np
+import torch
+
+import oracle
+from test_gpu_parity import sample_params, price_tol, assert_iv_close, dev
+
+CORNER = dict(kappa=[1e-3, 0.01, 2.0, 20.0], theta=[1e-3, 0.04, 0.25, 2.0], sigma=[1e-5, 1e-4, 1e-3, 1.0, 3.0, 5.0],
+              rho=[-0.999, -0.99, -0.95, 0.0, 0.95, 0.999], v0=[1e-3, 0.04, 0.25, 2.0])
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    nK = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 21, 31, 32, 33, 50, 63, 64, int(rng.integers(1, 65))]))
+    nT = int(rng.choice([1, 2, 3, 7, 8, 19, 20, 32, 33, 63, 64, int(rng.integers(1, 65))]))
+    kind = rng.integers(0, 5)
+    a = float(rng.uniform(0.02, 0.6))
+    if kind == 0: logm = np.linspace(-a, a, nK)
+    elif kind == 1: logm = np.linspace(-a, float(rng.uniform(0.02, 0.6)), nK)
+    elif kind == 2: logm = np.sort(rng.uniform(-a, a, nK))
+    elif kind == 3: logm = rng.uniform(-a, a, nK)
+    else: logm = np.round(rng.uniform(-a, a, nK), 1)            # repeated strikes
+    if nK == 1: logm = np.array([float(rng.uniform(-a, a))])
+    tk = rng.integers(0, 5)
+    if tk == 0: tau = np.round(np.linspace(rng.integers(5, 60), rng.integers(100, 1500), nT)) / 365.0
+    elif tk == 1: tau = np.sort(rng.uniform(0.004, 5.0, nT))
+    elif tk == 2: tau = rng.uniform(0.004, 3.0, nT)
+    elif tk == 3: tau = (rng.integers(7, 40) + rng.integers(20, 40) * np.arange(nT)) / 365.0   # one increment
+    else: tau = np.sort(np.concatenate([rng.uniform(0.0005, 0.01, min(2, nT)), rng.uniform(0.02, 2.0, max(nT - 2, 0))]))[:nT]
+    r = float(rng.choice([0.067, 0.0, -0.01, 0.03, 0.12]))
+    q = float(rng.choice([0.0, 0.0, 0.02, -0.005, 0.1]))
+    spot = float(rng.choice([1.0, 100.0, 7000.0, 21000.0, 1e5]))
+    variant = "A" if rng.random() < 0.6 else "B"
+    trunc = bool(rng.random() < 0.75)
+    per = nT * nK
+    N = int(rng.choice([1, 2, 6, 7, 8, 13, 14, 15, 29])) if per > 600 else int(rng.integers(1, 60))
+    p = sample_params(N, 1000 + seed)
+    for i in range(N):
+        if rng.random() < 0.25:
+            p[i] = [rng.choice(CORNER[k]) for k in ("kappa", "theta", "sigma", "rho", "v0")]
+    return dict(logm=logm, tau=tau, r=r, q=q, spot=spot, variant=variant, trunc=trunc, p=p,
+                desc=f"nK={nK} kind={kind} nT={nT} tk={tk} r={r} q={q} spot={spot} {variant} trunc={trunc} N={N}")
+
+
+def price_bad(got, ref, p, tau):
+    """Points whose price leaves the allowance.  The oracle follows the reference formula
+    operation by operation; its rounding noise grows as eps kappa theta T / sigma_v^2 on top of
+    eps / sigma_v^2 (a 50-digit evaluation of the corner rows kappa = 20, theta = 2, sigma_v = 1e-3
+    puts the kernel within an ulp and the oracle 1e-7 away), so the allowance scales with it.
+    At sigma_v = 1e-5 the reference switches to its series form, which returns values of 1e60 and
+    more for some rows: there both sides agree to 5-7 digits and the rule is relative; where it
+    overflows, the per-option sum of the oracle gives +-inf and the kernel's contraction (inf - inf)
+    NaN, and either inverts to a NaN vol."""
+    noise = 32 * np.finfo(float).eps / p[:, 2, None, None] ** 2 * \
+        np.maximum(1.0, (p[:, 0] * p[:, 1])[:, None, None] * np.abs(tau)[None, :, None])
+    tol = price_tol(ref) + noise + 1e-4 * np.abs(ref) * (np.abs(ref) > 10.0)
+    wild = lambda a: ~np.isfinite(a) | (np.abs(a) > 1e300)     # overflowed, or one doubling away from it
+    with np.errstate(invalid="ignore"):
+        return ~(np.abs(got - ref) <= tol) & ~(wild(got) & wild(ref))
+
+
+def run_case(afiv, c):
+    logm, tau, r, q, spot, v, p = c["logm"], c["tau"], c["r"], c["q"], c["spot"], c["variant"], c["p"]
+    g = afiv.Grid(logm, tau, r, q, trunc_days=c["trunc"])
+    ref = oracle.price_ratio_grid(p, logm, tau, r, q, c["trunc"])
+    got = g.price(dev(p)).cpu().numpy()
+    bad = price_bad(got, ref, p, tau)
+    assert not bad.any(), f"price: {bad.sum()} points, worst {np.nanmax(np.abs(got - ref)[bad]):.3g}"
+    iv, fl = g.implied_vol_checked(dev(ref), spot, v)
+    iv, fl = iv.cpu().numpy(), fl.cpu().numpy()
+    iv_o = oracle.implied_vol_grid(ref, logm, tau, spot, r, q, v)
+    if v == "A":
+        assert_iv_close(iv, iv_o, logm, tau, spot, r, q, max_ill_mismatch=0.01)
+    else:
+        mism = np.isnan(iv) != np.isnan(iv_o)
+        assert mism.mean() <= 0.01, f"variant B NaN mask differs at {mism.sum()} points"
+        m = ~np.isnan(iv) & ~np.isnan(iv_o)
+        d = np.abs(iv[m] - iv_o[m])
+        assert d.size == 0 or np.mean(d > 1e-6) <= 0.002, f"variant B: {np.sum(d > 1e-6)} of {d.size} roots differ"
+    fl_o = oracle.arb_check(iv, ref, logm, tau, spot, r, q, v)
+    assert np.array_equal(fl, fl_o), f"flags differ in {np.sum(np.any(fl != fl_o, axis=1))} surfaces"
+    iv2, fl2, ra2 = g.surface(dev(p), spot, v)
+    iv3, fl3 = g.implied_vol_checked(ra2, spot, v)
+    assert torch.equal(torch.nan_to_num(iv2, nan=-1.0), torch.nan_to_num(iv3, nan=-1.0)) and torch.equal(fl2, fl3), \
+        "afiv_surface differs from price + implied_vol_checked"
+    g.close()
