@@ -139,18 +139,19 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
 }
 
 // exp(-d T)
-__device__ __forceinline__ Cx cexp_neg(Cx d, double T)
+__device__ __forceinline__ Cx cexp_neg(Cx d, double T, const double *__restrict__ sct)
 {
     const double er = afivm::exp_core_f64(-d.r * T);
     double sn, cs;
-    afivm::sincos_f64(d.i * T, &sn, &cs);
+    afivm::sincos_tab_f64(d.i * T, sct, &sn, &cs);
     return {er * cs, -er * sn};
 }
 
 // One characteristic-function evaluation given ex = exp(-d T): returns (E sin alpha, E cos alpha)
 // with the discount factor of its integral folded in.
 __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, double phi, double wp,
-                                           double T, double ddt, double disc, Cx ex)
+                                           double T, double ddt, double disc, Cx ex,
+                                           const double *__restrict__ sct)
 {
     const Cx omex = {1.0 - ex.r, -ex.i};             // 1 - ex
     Cx A;
@@ -178,7 +179,7 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
     const double alpha = A.i + phi * ddt;
     const double E = wp * afivm::exp_core_f64(A.r) * disc;
     double sa, ca;
-    afivm::sincos_f64(alpha, &sa, &ca);
+    afivm::sincos_tab_f64(alpha, sct, &sa, &ca);
     return make_double2(E * sa, E * ca);
 }
 
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert((SYM ? 4 : 1) * KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
 
     __shared__ double lds[2 * XBUF];
+    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES];   // (sin, cos)(j pi/32)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
@@ -236,6 +238,9 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     const int64_t nchunks = (N + SPB - 1) / SPB;
     const int64_t my_chunks = blockIdx.x < nchunks ? (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int64_t total = my_chunks * ntiles;
+
+    afivm::load_sincos_table(sct);
+    __syncthreads();
 
     Model m = {};
     JState st0 = {}, st1 = {};
@@ -263,13 +268,13 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             st1 = cf_setup<1>(kappa, sigma, rho, m, phi);
             if (NFAC > 0) {
                 const double T0 = g.term[0];
-                ex0 = cexp_neg(st0.d, T0);
-                ex1 = cexp_neg(st1.d, T0);
-                fa0 = cexp_neg(st0.d, g.step_dt[0]);
-                fa1 = cexp_neg(st1.d, g.step_dt[0]);
+                ex0 = cexp_neg(st0.d, T0, sct);
+                ex1 = cexp_neg(st1.d, T0, sct);
+                fa0 = cexp_neg(st0.d, g.step_dt[0], sct);
+                fa1 = cexp_neg(st1.d, g.step_dt[0], sct);
                 if (NFAC > 1) {
-                    fb0 = cexp_neg(st0.d, g.step_dt[1]);
-                    fb1 = cexp_neg(st1.d, g.step_dt[1]);
+                    fb0 = cexp_neg(st0.d, g.step_dt[1], sct);
+                    fb1 = cexp_neg(st1.d, g.step_dt[1], sct);
                 }
             }
         }
@@ -335,12 +340,12 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             if (have_cur) {
                 double2 x0 = make_double2(0.0, 0.0);
                 if (t < nT) {
-                    if (NFAC == 0) ex0 = cexp_neg(st0.d, T);
+                    if (NFAC == 0) ex0 = cexp_neg(st0.d, T, sct);
                     else if (t > 0) {
                         ex0 = cmul(ex0, fa0);
                         for (int e = 0; e < extra; ++e) ex0 = cmul(ex0, fb0);
                     }
-                    x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq, ex0);
+                    x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq, ex0, sct);
                 }
                 if (sl < SPB) {   // spare lanes of the last wave own no row
                     if (SYM) {
@@ -355,12 +360,12 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             if (have_cur) {
                 double2 x1 = make_double2(0.0, 0.0);
                 if (t < nT) {
-                    if (NFAC == 0) ex1 = cexp_neg(st1.d, T);
+                    if (NFAC == 0) ex1 = cexp_neg(st1.d, T, sct);
                     else if (t > 0) {
                         ex1 = cmul(ex1, fa1);
                         for (int e = 0; e < extra; ++e) ex1 = cmul(ex1, fb1);
                     }
-                    x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr, ex1);
+                    x1 = cf_eval(st1, m, phi, wp, T, ddt, Dr, ex1, sct);
                 }
                 if (sl < SPB) {
                     if (SYM) {
@@ -437,11 +442,14 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
 __global__ void debug_math_kernel(int op, const double *__restrict__ x, const double *__restrict__ y, int64_t n,
                                   double *__restrict__ out0, double *__restrict__ out1)
 {
+    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES];
+    afivm::load_sincos_table(sct);
+    __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double a = 0.0, b = 0.0;
         switch (op) {
             case 0: a = afivm::exp_f64(x[i]); break;
-            case 1: afivm::sincos_f64(x[i], &a, &b); break;
+            case 1: afivm::sincos_tab_f64(x[i], sct, &a, &b); break;
             case 2: a = afivm::log1p_f64(x[i]); break;
             case 3: a = afivm::atan2_f64(x[i], y[i]); break;
             case 4: a = afivm::rcp_f64(x[i]); break;
