@@ -165,7 +165,7 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         const double inv = afivm::rcp_f64(1.0 + q);
         const Cx wz = cmul(w1, Cx{zr * inv, -w1.i * inv});                                    // w1 / (1 + w1)
         const Cx f1 = cmul(s.sum, wz);
-        const double glr = 0.5 * afivm::log1p_f64(q);
+        const double glr = 0.5 * afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);
         const double gli = afivm::atan2_f64(w1.i, zr);
         A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert((SYM ? 4 : 1) * KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
 
     __shared__ double lds[2 * XBUF];
-    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES];   // (sin, cos)(j pi/32)
+    // function tables: (sin, cos)(j pi/32), then the logarithm's (invc, logc)
+    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     const int64_t total = my_chunks * ntiles;
 
     afivm::load_sincos_table(sct);
+    afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
     __syncthreads();
 
     Model m = {};
@@ -442,15 +444,16 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
 __global__ void debug_math_kernel(int op, const double *__restrict__ x, const double *__restrict__ y, int64_t n,
                                   double *__restrict__ out0, double *__restrict__ out1)
 {
-    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES];
     afivm::load_sincos_table(sct);
+    afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
     __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double a = 0.0, b = 0.0;
         switch (op) {
             case 0: a = afivm::exp_f64(x[i]); break;
             case 1: afivm::sincos_tab_f64(x[i], sct, &a, &b); break;
-            case 2: a = afivm::log1p_f64(x[i]); break;
+            case 2: a = afivm::log1p_tab_f64(x[i], sct + afivm::SINCOS_TAB_DOUBLES); break;
             case 3: a = afivm::atan2_f64(x[i], y[i]); break;
             case 4: a = afivm::rcp_f64(x[i]); break;
             default: break;

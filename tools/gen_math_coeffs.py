@@ -15,6 +15,13 @@ Table-driven sincos (afivm::sincos_tab_f64): x = j pi/32 + r, |r| <= pi/64, tabl
 (sin, cos)(j pi/32), j < 64, correctly rounded; sin r and cos r - 1 by Taylor polynomials
 (remainders r^9/9! = 5e-18 and r^10/10! = 2e-20).
 
+
+Table-driven log1p (afivm::log1p_tab_f64): 1 + f = 2^k z with the high word of z in
+[LOGT_OFF_HI, LOGT_OFF_HI + 2^20), 128 bins of 2^13 high-word values each, laid out so that 1.0 is
+the middle of bin 80, whose entry is (1, 0) exactly: there r = z - 1 + c = f and the result keeps
+its relative accuracy as f -> 0.  Other bins: c_i = bin midpoint, invc_i = a double within 4e-9 of 1/c_i picked so that
+logc_i = -log invc_i is a double to 1e-4 ulp; r = z invc_i - 1 (one fma), |r| <= 2^-8, log1p r by Taylor to r^7.
+
 Writes csrc/afiv_math_coeffs.inc.
 """
 import os
@@ -66,6 +73,63 @@ def pa(z):
     return (mp.atan(t) / t - 1) / z
 
 
+LOGT_OFF_HI = 0x3fe5f000
+
+
+def log_table():
+    import struct
+    rows = []
+    for i in range(128):
+        lo = struct.unpack("<d", struct.pack("<Q", (LOGT_OFF_HI + i * 0x2000) << 32))[0]
+        hi = struct.unpack("<d", struct.pack("<Q", (LOGT_OFF_HI + (i + 1) * 0x2000) << 32))[0]
+        if lo < 1.0 < hi:
+            rows.append((1.0, 0.0))
+            continue
+        c = (mp.mpf(lo) + mp.mpf(hi)) / 2
+        # among the doubles next to 1/c take the one whose logarithm is closest to a double:
+        # the entry's rounding error then drops from half an ulp to about 1e-4 ulp
+        base = float(1 / c)
+        best = None
+        jr = np.random.default_rng(i)
+        for j in [0] + [int(v) for v in jr.integers(-20_000_000, 20_000_000, 3000)]:
+            # (offsets of up to 2e7 ulp, 4e-9 relative: a bin midpoint such as 255/256 moves its
+            # logarithm by a whole number of ulps per ulp, so nearby candidates all round alike)
+            cand = float(base + j * (np.nextafter(base, np.inf) - base))
+            lg = -mp.log(mp.mpf(cand))
+            err = abs((mp.mpf(float(lg)) - lg) / lg)
+            if best is None or err < best[0]:
+                best = (err, cand, float(lg))
+        rows.append((best[1], best[2]))
+    return rows
+
+
+def log1p_tab_model(f, rows, ln2hi, ln2lo):
+    """binary64 model of afivm::log1p_tab_f64 (np.float64 arithmetic, fma emulated in mpmath)."""
+    import struct
+
+    def fma(a, b, c):
+        return float(mp.mpf(a) * mp.mpf(b) + mp.mpf(c))
+    f = float(f)
+    u = 1.0 + f
+    c = f - (u - 1.0)
+    bits = struct.unpack("<Q", struct.pack("<d", u))[0]
+    hi = bits >> 32
+    tmp = hi - LOGT_OFF_HI
+    k = tmp >> 20                       # Python's >> floors: arithmetic shift
+    i = (tmp >> 13) & 127
+    zhi = hi - (k << 20)
+    z = struct.unpack("<d", struct.pack("<Q", (zhi << 32) | (bits & 0xffffffff)))[0]
+    invc, logc = rows[i]
+    r = fma(z, invc, -1.0)
+    r = fma(float(np.ldexp(c, -k)), invc, r)
+    p = 1.0 / 7
+    for cf in (-1.0 / 6, 1.0 / 5, -0.25, 1.0 / 3, -0.5):
+        p = fma(p, r, cf)
+    lg = fma(r * r, p, r)
+    kd = float(k)
+    return fma(kd, ln2hi, logc) + fma(kd, ln2lo, lg)
+
+
 def horner(c, z):
     acc = np.float64(c[-1])
     for v in c[-2::-1]:
@@ -109,6 +173,18 @@ def main():
         v = horner(Ed, r)
         ref = mp.exp(mp.mpf(r))
         worst["exp"] = max(worst["exp"], abs(float((mp.mpf(v) - ref) / ref)))
+    rows = log_table()
+    ln2 = mp.log(2)
+    l1 = float(ln2)
+    l2 = float(ln2 - mp.mpf(l1))
+    worst["log1p_tab"] = 0
+    fs = np.concatenate([rng.uniform(-0.95, 8, 6000), 10.0 ** rng.uniform(-20, 6, 2000), -(10.0 ** rng.uniform(-20, -0.1, 2000)),
+                         [2.0 ** -9 * s for s in (-1, -0.999, -1.001)], [2.0 ** -8 * s for s in (1, 0.999, 1.001)],
+                         rng.uniform(-0.01, 0.01, 3000)])
+    for f in fs:
+        ref = mp.log1p(mp.mpf(float(f)))
+        v = log1p_tab_model(f, rows, l1, l2)
+        worst["log1p_tab"] = max(worst["log1p_tab"], abs(float((mp.mpf(v) - ref) / ref)))
     print("float64 Horner accuracy (sin/cos absolute, others relative):")
     for k, v in worst.items():
         print(f"  {k:6s} {v:.3e}")
@@ -148,6 +224,11 @@ def main():
                         ("AFIV_COST_C0", float(mp.mpf(1) / 24)), ("AFIV_COST_C1", float(-mp.mpf(1) / 720)),
                         ("AFIV_COST_C2", float(mp.mpf(1) / 40320))):
             fh.write("#define %s %s\n" % (name, float(v).hex()))
+        fh.write("#define AFIV_LOGT_OFF_HI 0x%x\n" % LOGT_OFF_HI)
+        for i, v in enumerate((-0.5, mp.mpf(1) / 3, -0.25, mp.mpf(1) / 5, -mp.mpf(1) / 6, mp.mpf(1) / 7)):
+            fh.write("#define AFIV_LOGT_C%d %s\n" % (i, float(v).hex()))
+        fh.write("#define AFIV_LOG_TAB_LIST \\\n")
+        fh.write(", \\\n".join("  %s, %s" % (a.hex(), b.hex()) for a, b in rows) + "\n")
         fh.write("#define AFIV_SINCOS_TAB_LIST \\\n")
         rows = ["  %s, %s" % (float(mp.sin(j * pio32)).hex(), float(mp.cos(j * pio32)).hex()) for j in range(64)]
         fh.write(", \\\n".join(rows) + "\n")
