@@ -41,8 +41,9 @@ __device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ 
     const double x = a * sqrth;
     const double u = fmin(fabs(x), 40.0);           // erfc(40) = 0 in double; also maps NaN to a finite dummy
     const double t = 64.0 * afivm::rcp_f64(1.0 + u);
-    const int seg = (int)fmin(t, 63.0);
-    const double f = (t - (double)seg) - 0.5;
+    const double tc = fmin(t, 0x1.fffffffffffffp5);      // t = 64 (u = 0) belongs to the last segment
+    const int seg = (int)tc;
+    const double f = __builtin_amdgcn_fract(tc) - 0.5;
     const double *c = tab + seg * ERFCX_ROW;
     double p = c[8];
     p = fma(p, f, c[7]);
@@ -92,8 +93,9 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 // Segment and local coordinate of erfcx's table for t = 64/(1 + u) (see ndtr_dev).
 __device__ __forceinline__ const d2v *erfcx_row(double t, const double *__restrict__ tab, double *f)
 {
-    const int seg = (int)fmin(t, 63.0);
-    *f = (t - (double)seg) - 0.5;
+    const double tc = fmin(t, 0x1.fffffffffffffp5);      // t = 64 (u = 0) belongs to the last segment
+    const int seg = (int)tc;
+    *f = __builtin_amdgcn_fract(tc) - 0.5;
     // 24-bit multiply: full rate, where a 32-bit v_mul_lo_u32 runs at a quarter of it
     return reinterpret_cast<const d2v *>(tab + __mul24(seg, ERFCX_ROW));   // rows are 80 bytes: 16-byte aligned
 }
