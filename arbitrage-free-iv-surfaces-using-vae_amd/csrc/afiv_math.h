@@ -4,16 +4,19 @@
 // 155 / 100 vector instructions each and carry a Payne-Hanek reduction and special-value handling
 // that these kernels never need but whose registers are allocated all the same.  The functions
 // below have ONE code path (no data-dependent branches, so a wave never executes two variants back
-// to back), assume finite arguments of moderate size, and cost 20-50 instructions.
+// to back), assume finite arguments of moderate size, and cost 20-30 instructions: sincos, log1p
+// and atan2 reduce their argument against a small table that the kernel keeps in LDS (1, 2 and
+// 4 KB; load_*_table), which leaves a polynomial of degree 3-7 on an interval of 2^-8..2^-5
+// instead of degree 11-23 on the classical one.
 //
 // Accuracy (tests/test_gpu_math.py checks each against 50-digit references):
-//   exp_f64      relative 2 ulp for x in [-745, 709]; 0 below, +inf above
-//   sincos_f64   ABSOLUTE error <= 3e-16 for |x| < 1e9 (3-term Cody-Waite; sin and cos only ever
-//                multiply an amplitude here, so absolute error is what matters)
-//   log1p_f64    relative 2 ulp for f > -1 (relative accuracy near f = 0 is the point: the
-//                characteristic function divides this logarithm by sigma_v^2)
-//   atan2_f64    relative 2 ulp, all quadrants, finite arguments not both zero
-//   rcp_f64      relative 1 ulp for normal x (v_rcp_f64 + two Newton steps)
+//   exp_f64         relative 2 ulp for x in [-745, 709]; 0 below, +inf above
+//   sincos_tab_f64  ABSOLUTE error <= 3e-16 for |x| < 1e9 (two-term Cody-Waite; sin and cos only
+//                   ever multiply an amplitude here, so absolute error is what matters)
+//   log1p_tab_f64   relative 2 ulp for f > -1 (relative accuracy near f = 0 is the point: the
+//                   characteristic function divides this logarithm by sigma_v^2)
+//   atan2_tab_f64   relative 2 ulp, all quadrants, finite arguments not both zero
+//   rcp_f64         relative 1 ulp for normal x (v_rcp_f64 + two Newton steps)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,18 +27,14 @@ namespace afivm {
 // Polynomial coefficients live in constant memory and are fetched where they are used, with scalar
 // loads, so that the FMAs read them as scalar operands.  f64 instructions take no 64-bit literal:
 // written as literals each coefficient would be copied into a vector register pair, and hoisted
-// out of the kernels' loops those 45 pairs (or, hoisted as scalars, 90 scalar registers) end up
+// out of the kernels' loops those pairs (or, hoisted as scalars, twice as many scalar registers) end up
 // spilled.  coeffs() hands out the table's address through an empty asm statement that names a
 // value the caller has just computed: the compiler cannot prove the address loop-invariant, nor
 // move the loads above that value, so each polynomial's coefficients are live only around it.
-#define AFIV_C6(P) P##0, P##1, P##2, P##3, P##4, P##5
-enum { OFF_SIN = 0, OFF_COS = 6, OFF_LOG = 12, OFF_ATAN = 20, OFF_EXP = 32, OFF_SINT = 48, OFF_COST = 51, OFF_LOGT = 54, N_COEF = 64 };
+enum { OFF_EXP = 0, OFF_SINT = 16, OFF_COST = 19, OFF_LOGT = 22, N_COEF = 32 };
 inline __constant__ __attribute__((aligned(64))) double c_tab[N_COEF] = {
-    AFIV_C6(AFIV_SIN_C), AFIV_C6(AFIV_COS_C),
-    AFIV_C6(AFIV_LOG_C), AFIV_LOG_C6, 0.0,
-    AFIV_C6(AFIV_ATAN_C), AFIV_ATAN_C6, AFIV_ATAN_C7, AFIV_ATAN_C8, AFIV_ATAN_C9, AFIV_ATAN_C10, AFIV_ATAN_C11,
-    AFIV_C6(AFIV_EXP_C), AFIV_EXP_C6, AFIV_EXP_C7, AFIV_EXP_C8, AFIV_EXP_C9, AFIV_EXP_C10, AFIV_EXP_C11,
-    AFIV_EXP_C12, AFIV_EXP_C13, 0.0, 0.0,
+    AFIV_EXP_C0, AFIV_EXP_C1, AFIV_EXP_C2, AFIV_EXP_C3, AFIV_EXP_C4, AFIV_EXP_C5, AFIV_EXP_C6, AFIV_EXP_C7,
+    AFIV_EXP_C8, AFIV_EXP_C9, AFIV_EXP_C10, AFIV_EXP_C11, AFIV_EXP_C12, AFIV_EXP_C13, 0.0, 0.0,
     AFIV_SINT_C0, AFIV_SINT_C1, AFIV_SINT_C2, AFIV_COST_C0, AFIV_COST_C1, AFIV_COST_C2,
     AFIV_LOGT_C0, AFIV_LOGT_C1, AFIV_LOGT_C2, AFIV_LOGT_C3, AFIV_LOGT_C4, AFIV_LOGT_C5, 0.0, 0.0, 0.0, 0.0};
 
@@ -136,49 +135,11 @@ __device__ __forceinline__ double exp_f64(double x)
     return x != x ? x : y;
 }
 
-// sin and cos of the same argument.
-__device__ __forceinline__ void sincos_f64(double x, double *s_out, double *c_out)
-{
-    const double k = __builtin_rint(x * AFIV_TWO_OVER_PI);
-    double r = __builtin_fma(k, -AFIV_PIO2_1, x);
-    r = __builtin_fma(k, -AFIV_PIO2_2, r);
-    r = __builtin_fma(k, -AFIV_PIO2_3, r);
-    const int q = (int)k;
-    const double z = r * r;
-    const coef_ptr c_sin = coeffs(z) + OFF_SIN;
-    const coef_ptr c_cos = c_sin + (OFF_COS - OFF_SIN);
-    double ps = c_sin[5];
-    ps = fma_sc(ps, z, c_sin[4]);
-    ps = fma_sc(ps, z, c_sin[3]);
-    ps = fma_sc(ps, z, c_sin[2]);
-    ps = fma_sc(ps, z, c_sin[1]);
-    ps = fma_sc(ps, z, c_sin[0]);
-    const double sn = __builtin_fma(r * z, ps, r);
-    double pc = c_cos[5];
-    pc = fma_sc(pc, z, c_cos[4]);
-    pc = fma_sc(pc, z, c_cos[3]);
-    pc = fma_sc(pc, z, c_cos[2]);
-    pc = fma_sc(pc, z, c_cos[1]);
-    pc = fma_sc(pc, z, c_cos[0]);
-    const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    // quadrant: x = r + q pi/2.  Odd q swaps the two; the signs are bit 1 of q (sin) and of
-    // q + 1 (cos) moved into the sign bit.
-    const bool swap = q & 1;
-    const double s0 = swap ? cs : sn;
-    const double c0 = swap ? sn : cs;
-    const unsigned qs = (unsigned)q << 30;
-    const double s = __hiloint2double(__double2hiint(s0) ^ (int)(qs & 0x80000000u), __double2loint(s0));
-    const double c = __hiloint2double(__double2hiint(c0) ^ (int)((qs + 0x40000000u) & 0x80000000u),
-                                      __double2loint(c0));
-    *s_out = s;
-    *c_out = c;
-}
-
 // sin and cos of the same argument through a 64-entry table in LDS: x = j pi/32 + r with
 // |r| <= pi/64, (S, C) = (sin, cos)(j pi/32) from the table, and
 //   sin x = S + (S (cos r - 1) + C sin r),   cos x = C + (C (cos r - 1) - S sin r)
-// with two short Taylor polynomials: no quadrant logic, half the polynomial work of sincos_f64
-// (21 vector instructions and one 16-byte LDS read instead of 34).  Same absolute accuracy:
+// with two short Taylor polynomials: no quadrant logic and half the polynomial work of the
+// classical pi/2 reduction (21 vector instructions and one 16-byte LDS read instead of 34).  Same absolute accuracy:
 // the table entries are correctly rounded and the corrections are below pi/64 in size.
 // `tab` is SINCOS_TAB_DOUBLES doubles filled by load_sincos_table.
 constexpr int SINCOS_TAB_DOUBLES = 128;
@@ -214,39 +175,6 @@ __device__ __forceinline__ void sincos_tab_f64(double x, const double *__restric
     *c_out = __builtin_fma(t.y, dc, __builtin_fma(-t.x, sr, t.y));
 }
 
-// log(1 + f).  For |f| small the argument is used as is (exact); otherwise 1 + f is split into
-// m 2^e with m in [sqrt(1/2), sqrt(2)) and the rounding of 1 + f is corrected to first order.
-__device__ __forceinline__ double log1p_f64(double f)
-{
-    const double u = 1.0 + f;
-    // c = f - (u - 1): what the rounding of 1 + f lost (exact when |f| <= 1)
-    const double c = (f - (u - 1.0));
-    int e = __builtin_amdgcn_frexp_exp(u);                      // u = mant 2^e, mant in [0.5, 1)
-    double m = __builtin_amdgcn_frexp_mant(u);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m + m : m;
-    e = low ? e - 1 : e;
-    // g = m - 1 (exact), plus the correction term scaled like m
-    const double scale = __builtin_ldexp(1.0, -e);
-    const bool small = e == 0;
-    // when e == 0, m == u and (m - 1) + c == f up to the rounding already inside f itself
-    const double g = small ? f : __builtin_fma(c, scale, m - 1.0);
-    const double s = g * rcp_f64(2.0 + g);
-    const double z = s * s;
-    const coef_ptr c_log = coeffs(z) + OFF_LOG;
-    double p = c_log[6];
-    p = fma_sc(p, z, c_log[5]);
-    p = fma_sc(p, z, c_log[4]);
-    p = fma_sc(p, z, c_log[3]);
-    p = fma_sc(p, z, c_log[2]);
-    p = fma_sc(p, z, c_log[1]);
-    p = fma_sc(p, z, c_log[0]);
-    // log(1+g) = 2 atanh(s) = 2 s + s z P(z) = g - s (g - z P(z))
-    const double lg = g - s * (g - z * p);
-    const double ed = (double)e;
-    return __builtin_fma(ed, AFIV_LN2_HI, __builtin_fma(ed, AFIV_LN2_LO, lg));
-}
-
 // log(1 + f) through a 128-entry table in LDS.  u = fl(1 + f) = 2^k z with the high word of z in
 // [AFIV_LOGT_OFF_HI, AFIV_LOGT_OFF_HI + 2^20), i.e. z in [0.6855, 1.371); bin i = bits 13..19 of
 // that offset; the table holds (invc_i, logc_i = -log invc_i) with invc_i next to the reciprocal
@@ -256,7 +184,7 @@ __device__ __forceinline__ double log1p_f64(double f)
 // exactly, so there r = f and the result is as accurate, relatively, as the seven-term series:
 // the characteristic function divides this logarithm by sigma_v^2, so relative accuracy near
 // f = 0 is the point.  27 vector instructions and one 16-byte LDS read, no reciprocal, against 44
-// for log1p_f64; relative error <= 1 ulp (tools/gen_math_coeffs.py measures a binary64 model).
+// for the atanh-series form on [sqrt(1/2), sqrt(2)); relative error <= 1 ulp (tools/gen_math_coeffs.py measures a binary64 model).
 // f > -1, finite.  `tab` is LOG_TAB_DOUBLES doubles filled by load_log_table.
 constexpr int LOG_TAB_DOUBLES = 256;
 inline __constant__ __attribute__((aligned(16))) double c_log_tab[LOG_TAB_DOUBLES] = {AFIV_LOG_TAB_LIST};
@@ -291,32 +219,43 @@ __device__ __forceinline__ double log1p_tab_f64(double f, const double *__restri
     return __builtin_fma(kd, AFIV_LN2_HI, t.y) + __builtin_fma(kd, AFIV_LN2_LO, lg);
 }
 
-// atan2(y, x) for finite arguments, not both zero.
-__device__ __forceinline__ double atan2_f64(double y, double x)
+// atan2(y, x) through a 65-row table in LDS: t = min(|x|,|y|)/max(|x|,|y|) in [0, 1], j = rint(64 t),
+// h = t - j/64 (exact), atan t = sum_{k<8} A[j][k] h^k; row 0 is the odd Taylor series with exact
+// 0 and 1, so small angles keep their relative accuracy.  No second reduction (the classical
+// (t-1)/(t+1) step above tan(pi/8)) and a degree-7 instead of a degree-23 polynomial: 29 vector instructions and
+// four 16-byte LDS reads against 47.  Relative error <= 2 ulp (the quotient's ulp included).
+// Finite arguments, not both zero.  `tab` is ATAN_TAB_DOUBLES doubles filled by load_atan_table.
+constexpr int ATAN_TAB_DOUBLES = 65 * 8;
+inline __constant__ __attribute__((aligned(16))) double c_atan_tab[ATAN_TAB_DOUBLES] = {AFIV_ATAN_TAB_LIST};
+
+__device__ __forceinline__ void load_atan_table(double *lds_tab)
 {
+    for (int i = threadIdx.x; i < ATAN_TAB_DOUBLES; i += blockDim.x) lds_tab[i] = c_atan_tab[i];
+}
+
+__device__ __forceinline__ double atan2_tab_f64(double y, double x, const double *__restrict__ tab)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
     const double ax = fabs(x), ay = fabs(y);
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-    // t = mn/mx in [0,1]; above tan(pi/8) use atan t = pi/4 + atan((t-1)/(t+1)) with one division
-    const bool hi = mn > AFIV_TAN_PIO8 * mx;
-    const double num = hi ? mn - mx : mn;
-    const double den = hi ? mn + mx : mx;
-    const double t = num * rcp_f64(den);
-    const double z = t * t;
-    const coef_ptr c_atan = coeffs(z) + OFF_ATAN;
-    double p = c_atan[11];
-    p = fma_sc(p, z, c_atan[10]);
-    p = fma_sc(p, z, c_atan[9]);
-    p = fma_sc(p, z, c_atan[8]);
-    p = fma_sc(p, z, c_atan[7]);
-    p = fma_sc(p, z, c_atan[6]);
-    p = fma_sc(p, z, c_atan[5]);
-    p = fma_sc(p, z, c_atan[4]);
-    p = fma_sc(p, z, c_atan[3]);
-    p = fma_sc(p, z, c_atan[2]);
-    p = fma_sc(p, z, c_atan[1]);
-    p = fma_sc(p, z, c_atan[0]);
-    double a = __builtin_fma(t * z, p, t);                      // atan of the reduced argument
-    a = hi ? a + AFIV_PIO4 : a;                                 // angle of (mx, mn) in [0, pi/4]
+    const double t = mn * rcp_f64(mx);
+    const double shifted = __builtin_fma(t, 64.0, 0x1.8p52);   // low word = rint(64 t)
+    const double kd = shifted - 0x1.8p52;
+    const double h = __builtin_fma(kd, -0x1p-6, t);
+    const unsigned j = min((unsigned)__double2loint(shifted), 64u);   // (a NaN quotient must not index past the table)
+    const d2 *row = reinterpret_cast<const d2 *>(tab) + 4 * j;
+    // the row is read in two halves so that four, not eight, coefficient registers are live
+    const d2 c45 = row[2], c67 = row[3];
+    double a = c67.y;
+    a = __builtin_fma(a, h, c67.x);
+    a = __builtin_fma(a, h, c45.y);
+    a = __builtin_fma(a, h, c45.x);
+    asm volatile("" : "+v"(a));
+    const d2 c01 = row[0], c23 = row[1];
+    a = __builtin_fma(a, h, c23.y);
+    a = __builtin_fma(a, h, c23.x);
+    a = __builtin_fma(a, h, c01.y);
+    a = __builtin_fma(a, h, c01.x);                             // angle of (mx, mn) in [0, pi/4]
     a = ay > ax ? 2.0 * AFIV_PIO4 - a : a;                      // first octant pair
     a = x < 0.0 ? AFIV_PI - a : a;
     return __builtin_copysign(a, y);

@@ -54,6 +54,7 @@ constexpr int XBUF = ROWS * XSTRIDE;       // doubles per operand buffer
 static_assert(SPB * MT <= ROWS && SPB * NQ <= THREADS, "row / lane layout");
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int FTAB_DOUBLES = afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES + afivm::ATAN_TAB_DOUBLES;   // function tables in LDS
 
 __constant__ double c_lag_x[NQ] = {AFIV_LAG_X_LIST};
 __constant__ double c_lag_wp[NQ] = {AFIV_LAG_WP_LIST};   // W_n / (pi x_n)
@@ -166,7 +167,7 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         const Cx wz = cmul(w1, Cx{zr * inv, -w1.i * inv});                                    // w1 / (1 + w1)
         const Cx f1 = cmul(s.sum, wz);
         const double glr = 0.5 * afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);
-        const double gli = afivm::atan2_f64(w1.i, zr);
+        const double gli = afivm::atan2_tab_f64(w1.i, zr, sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
         A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
     } else {
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert((SYM ? 4 : 1) * KS * ROWS * NKP <= XBUF, "partial tiles must fit in one operand buffer");
 
     __shared__ double lds[2 * XBUF];
-    // function tables: (sin, cos)(j pi/32), then the logarithm's (invc, logc)
-    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES];
+    // function tables: (sin, cos)(j pi/32), the logarithm's (invc, logc), the arctangent's rows
+    __shared__ __attribute__((aligned(16))) double sct[FTAB_DOUBLES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
 
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
+    afivm::load_atan_table(sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
     __syncthreads();
 
     Model m = {};
@@ -444,9 +446,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
 __global__ void debug_math_kernel(int op, const double *__restrict__ x, const double *__restrict__ y, int64_t n,
                                   double *__restrict__ out0, double *__restrict__ out1)
 {
-    __shared__ __attribute__((aligned(16))) double sct[afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double sct[FTAB_DOUBLES];
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
+    afivm::load_atan_table(sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
     __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double a = 0.0, b = 0.0;
@@ -454,7 +457,7 @@ __global__ void debug_math_kernel(int op, const double *__restrict__ x, const do
             case 0: a = afivm::exp_f64(x[i]); break;
             case 1: afivm::sincos_tab_f64(x[i], sct, &a, &b); break;
             case 2: a = afivm::log1p_tab_f64(x[i], sct + afivm::SINCOS_TAB_DOUBLES); break;
-            case 3: a = afivm::atan2_f64(x[i], y[i]); break;
+            case 3: a = afivm::atan2_tab_f64(x[i], y[i], sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES); break;
             case 4: a = afivm::rcp_f64(x[i]); break;
             default: break;
         }

@@ -1,14 +1,8 @@
 #!/usr/bin/env python3
-"""Generate polynomial coefficients for the kernel's own FP64 elementary functions.
+"""Generate the constants of the kernels' own FP64 elementary functions (csrc/afiv_math.h):
+polynomial coefficients and reduction tables, 60-digit arithmetic (mpmath), each rounded once to
+binary64; binary64 models of the table-driven functions are checked against mpmath below.
 
-Each kernel polynomial is the Chebyshev interpolant (60-digit arithmetic, mpmath) of the smooth
-remainder of the function on the reduced interval, re-expanded in the monomial basis and rounded
-once to binary64.  Near-minimax; the float64 Horner evaluation is checked below against mpmath.
-
-  sin r = r + r z PS(z)              z = r^2, |r| <= pi/4 (+2 % margin)        PS degree 5
-  cos r = 1 - z/2 + z^2 PC(z)                                                    PC degree 5
-  log(1+f) = f - s (f - z PL(z))     s = f/(2+f), z = s^2, f in [sqrt(1/2)-1, sqrt(2)-1]   PL degree 6
-  atan t = t + t z PA(z)             z = t^2, |t| <= tan(pi/8) (+2 % margin)    PA degree 11
   exp r  = sum_{k<=13} r^k / k!      |r| <= ln(2)/2  (plain Taylor: remainder 4e-18)
 
 Table-driven sincos (afivm::sincos_tab_f64): x = j pi/32 + r, |r| <= pi/64, table of
@@ -21,6 +15,11 @@ Table-driven log1p (afivm::log1p_tab_f64): 1 + f = 2^k z with the high word of z
 the middle of bin 80, whose entry is (1, 0) exactly: there r = z - 1 + c = f and the result keeps
 its relative accuracy as f -> 0.  Other bins: c_i = bin midpoint, invc_i = a double within 4e-9 of 1/c_i picked so that
 logc_i = -log invc_i is a double to 1e-4 ulp; r = z invc_i - 1 (one fma), |r| <= 2^-8, log1p r by Taylor to r^7.
+
+Table-driven arctangent (afivm::atan2_tab_f64): t = min/max in [0, 1], j = rint(64 t), h = t - j/64,
+atan t = sum_{k<8} A[j][k] h^k with |h| <= 1/128.  Row 0 is the odd Taylor series (0, 1, 0, -1/3,
+0, 1/5, 0, -1/7: exact 0 and 1, so the result keeps its relative accuracy as t -> 0); rows 1..64
+are degree-7 Chebyshev interpolants of atan about j/64 (error 1e-20).
 
 Writes csrc/afiv_math_coeffs.inc.
 """
@@ -42,35 +41,6 @@ def cheb_fit(fun, lo, hi, deg):
             A[i, j] = x ** j
     c = mp.lu_solve(A, mp.matrix([fun(x) for x in nodes]))
     return [c[j] for j in range(n)]
-
-
-def ps(z):
-    if z == 0:
-        return -mp.mpf(1) / 6
-    r = mp.sqrt(z)
-    return (mp.sin(r) / r - 1) / z
-
-
-def pc(z):
-    if z == 0:
-        return mp.mpf(1) / 24
-    r = mp.sqrt(z)
-    return (mp.cos(r) - 1 + z / 2) / (z * z)
-
-
-def pl(z):
-    # 2 atanh(s) = 2 s + s z PL(z)
-    if z == 0:
-        return mp.mpf(2) / 3
-    s = mp.sqrt(z)
-    return (2 * mp.atanh(s) / s - 2) / z
-
-
-def pa(z):
-    if z == 0:
-        return -mp.mpf(1) / 3
-    t = mp.sqrt(z)
-    return (mp.atan(t) / t - 1) / z
 
 
 LOGT_OFF_HI = 0x3fe5f000
@@ -130,6 +100,27 @@ def log1p_tab_model(f, rows, ln2hi, ln2lo):
     return fma(kd, ln2hi, logc) + fma(kd, ln2lo, lg)
 
 
+def atan_table():
+    rows = [[0, 1, 0, -mp.mpf(1) / 3, 0, mp.mpf(1) / 5, 0, -mp.mpf(1) / 7]]
+    a = mp.mpf(1) / 128
+    for j in range(1, 65):
+        tj = mp.mpf(j) / 64
+        rows.append(cheb_fit(lambda h: mp.atan(tj + h), -a * mp.mpf("1.01"), a * mp.mpf("1.01"), 7))
+    return [[float(v) for v in r] for r in rows]
+
+
+def atan_tab_model(t, rows):
+    def fma(a, b, c):
+        return float(mp.mpf(a) * mp.mpf(b) + mp.mpf(c))
+    j = int(np.rint(t * 64.0))
+    h = fma(float(j), -1.0 / 64, t)
+    c = rows[j]
+    p = c[7]
+    for k in range(6, -1, -1):
+        p = fma(p, h, c[k])
+    return p
+
+
 def horner(c, z):
     acc = np.float64(c[-1])
     for v in c[-2::-1]:
@@ -139,36 +130,12 @@ def horner(c, z):
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    zmax_trig = (mp.pi / 4 * mp.mpf("1.02")) ** 2
-    S = cheb_fit(ps, mp.mpf(0), zmax_trig, 5)
-    C = cheb_fit(pc, mp.mpf(0), zmax_trig, 5)
-    smax = (mp.sqrt(2) - 1) / (mp.sqrt(2) + 1)
-    L = cheb_fit(pl, mp.mpf(0), (smax * mp.mpf("1.02")) ** 2, 6)
-    tmax = (mp.sqrt(2) - 1) * mp.mpf("1.02")
-    A = cheb_fit(pa, mp.mpf(0), tmax ** 2, 11)
     E = [1 / mp.factorial(k) for k in range(14)]
 
     rng = np.random.default_rng(1)
     # ---- float64 accuracy checks against mpmath ------------------------------------------------
-    Sd, Cd, Ld, Ad, Ed = ([float(v) for v in X] for X in (S, C, L, A, E))
-    worst = {"sin": 0, "cos": 0, "log1p": 0, "atan": 0, "exp": 0}
-    for r in rng.uniform(-np.pi / 4, np.pi / 4, 4000):
-        z = r * r
-        s = r + r * z * horner(Sd, z)
-        c = 1.0 - 0.5 * z + z * z * horner(Cd, z)
-        worst["sin"] = max(worst["sin"], abs(float(mp.mpf(s) - mp.sin(mp.mpf(r)))))
-        worst["cos"] = max(worst["cos"], abs(float(mp.mpf(c) - mp.cos(mp.mpf(r)))))
-    for f in np.concatenate([rng.uniform(np.sqrt(0.5) - 1, np.sqrt(2) - 1, 4000), 10.0 ** rng.uniform(-12, -1, 500)]):
-        s = f / (2.0 + f)
-        z = s * s
-        v = f - s * (f - z * horner(Ld, z))
-        ref = mp.log1p(mp.mpf(f))
-        worst["log1p"] = max(worst["log1p"], abs(float((mp.mpf(v) - ref) / ref)))
-    for t in np.concatenate([rng.uniform(-float(tmax), float(tmax), 4000), 10.0 ** rng.uniform(-12, -1, 500)]):
-        z = t * t
-        v = t + t * z * horner(Ad, z)
-        ref = mp.atan(mp.mpf(t))
-        worst["atan"] = max(worst["atan"], abs(float((mp.mpf(v) - ref) / ref)))
+    Ed = [float(v) for v in E]
+    worst = {"exp": 0}
     for r in rng.uniform(-np.log(2) / 2, np.log(2) / 2, 4000):
         v = horner(Ed, r)
         ref = mp.exp(mp.mpf(r))
@@ -185,34 +152,30 @@ def main():
         ref = mp.log1p(mp.mpf(float(f)))
         v = log1p_tab_model(f, rows, l1, l2)
         worst["log1p_tab"] = max(worst["log1p_tab"], abs(float((mp.mpf(v) - ref) / ref)))
-    print("float64 Horner accuracy (sin/cos absolute, others relative):")
+    arows = atan_table()
+    worst["atan_tab"] = 0
+    for t in np.concatenate([rng.uniform(0, 1, 8000), 10.0 ** rng.uniform(-15, -1, 1500), [1.0, 1.0 / 128, 3.0 / 128, 0.5]]):
+        ref = mp.atan(mp.mpf(float(t)))
+        worst["atan_tab"] = max(worst["atan_tab"], abs(float((mp.mpf(atan_tab_model(float(t), arows)) - ref) / ref)))
+    print("binary64 accuracy (relative):")
     for k, v in worst.items():
         print(f"  {k:6s} {v:.3e}")
 
     out = os.path.join(root, "arbitrage-free-iv-surfaces-using-vae_amd", "csrc", "afiv_math_coeffs.inc")
     with open(out, "w") as fh:
         fh.write("/* Generated by tools/gen_math_coeffs.py -- do not edit.\n"
-                 " * Polynomial kernels of the FP64 elementary functions in afiv_math.h (binary64 hex).\n"
-                 " * Measured float64 accuracy: sin %.1e, cos %.1e (absolute, |r| <= pi/4);\n"
-                 " * log1p %.1e, atan %.1e, exp %.1e (relative, on their reduced intervals). */\n"
-                 % (worst["sin"], worst["cos"], worst["log1p"], worst["atan"], worst["exp"]))
-        for name, vals in (("AFIV_SIN_C", S), ("AFIV_COS_C", C), ("AFIV_LOG_C", L), ("AFIV_ATAN_C", A),
-                           ("AFIV_EXP_C", E)):
+                 " * Constants of the FP64 elementary functions in afiv_math.h (binary64 hex).\n"
+                 " * Measured binary64 accuracy (relative): exp %.1e on its reduced interval, log1p table %.1e,\n"
+                 " * atan table %.1e. */\n" % (worst["exp"], worst["log1p_tab"], worst["atan_tab"]))
+        for name, vals in (("AFIV_EXP_C", E),):
             fh.write("#define %s_N %d\n" % (name, len(vals)))
             for i, v in enumerate(vals):
                 fh.write("#define %s%d %s\n" % (name, i, float(v).hex()))
-        # pi/2 in three pieces for the Cody-Waite reduction, ln 2 in two, and friends
-        pio2 = mp.pi / 2
-        p1 = float(pio2)
-        p2 = float(pio2 - mp.mpf(p1))
-        p3 = float(pio2 - mp.mpf(p1) - mp.mpf(p2))
         ln2 = mp.log(2)
         l1 = float(ln2)
         l2 = float(ln2 - mp.mpf(l1))
-        for name, v in (("AFIV_PIO2_1", p1), ("AFIV_PIO2_2", p2), ("AFIV_PIO2_3", p3),
-                        ("AFIV_TWO_OVER_PI", float(2 / mp.pi)), ("AFIV_LN2_HI", l1), ("AFIV_LN2_LO", l2),
-                        ("AFIV_LOG2E", float(1 / ln2)), ("AFIV_PI", float(mp.pi)),
-                        ("AFIV_PIO4", float(mp.pi / 4)), ("AFIV_TAN_PIO8", float(mp.sqrt(2) - 1))):
+        for name, v in (("AFIV_LN2_HI", l1), ("AFIV_LN2_LO", l2), ("AFIV_LOG2E", float(1 / ln2)),
+                        ("AFIV_PI", float(mp.pi)), ("AFIV_PIO4", float(mp.pi / 4))):
             fh.write("#define %s %s\n" % (name, float(v).hex()))
         # table-driven sincos: pi/32 in two pieces, Taylor coefficients, (sin, cos)(j pi/32)
         pio32 = mp.pi / 32
@@ -224,6 +187,8 @@ def main():
                         ("AFIV_COST_C0", float(mp.mpf(1) / 24)), ("AFIV_COST_C1", float(-mp.mpf(1) / 720)),
                         ("AFIV_COST_C2", float(mp.mpf(1) / 40320))):
             fh.write("#define %s %s\n" % (name, float(v).hex()))
+        fh.write("#define AFIV_ATAN_TAB_LIST \\\n")
+        fh.write(", \\\n".join("  " + ", ".join(v.hex() for v in r) for r in arows) + "\n")
         fh.write("#define AFIV_LOGT_OFF_HI 0x%x\n" % LOGT_OFF_HI)
         for i, v in enumerate((-0.5, mp.mpf(1) / 3, -0.25, mp.mpf(1) / 5, -mp.mpf(1) / 6, mp.mpf(1) / 7)):
             fh.write("#define AFIV_LOGT_C%d %s\n" % (i, float(v).hex()))
