@@ -219,6 +219,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     __shared__ double lds[2 * XBUF];
     // function tables: (sin, cos)(j pi/32), the logarithm's (invc, logc), the arctangent's rows
     __shared__ __attribute__((aligned(16))) double sct[FTAB_DOUBLES];
+    __shared__ double ecst[4][AFIV_MAX_STRIKES];     // K_k | Dq_t | Dr_t | 1/exp(-r tau_t) (0: expired)
+    static_assert(AFIV_MAX_STRIKES == AFIV_MAX_MATURITIES, "one row length for both");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
@@ -244,6 +246,13 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
     afivm::load_atan_table(sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
+    if (tid < nK) ecst[0][tid] = g.Kmult[tid];
+    if (tid < nT) {
+        ecst[1][tid] = g.Dq[tid];
+        ecst[2][tid] = g.Dr[tid];
+        // price -> ratio: divide by exp(-r tau); an expired option has NPV 0 whatever its sums
+        ecst[3][tid] = g.term[tid] > 0.0 ? 1.0 / g.disc_tau[tid] : 0.0;
+    }
     __syncthreads();
 
     Model m = {};
@@ -390,18 +399,26 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             for (int i = 0; i < 4; ++i) pw[((lane >> 4) + 4 * i) * NKP] = acc[i];
         }
         __syncthreads();
-        if (SYM) {
-            // item = (row, half-strike k, direct | mirror image)
-            for (int o = tid; have_prev && o < ROWS * NKP * 2; o += THREADS) {
-                const int row = o / (2 * NKP);
-                const int rem = o - row * (2 * NKP);
+        // One output item per thread.  Everything an item needs besides the partial tiles comes
+        // from the constants staged in LDS at kernel start and from 32-bit index arithmetic on
+        // top of one wave-uniform 64-bit base: between the two barriers around this block every
+        // wave waits, so a chain of table loads from global memory here is exposed latency.
+        static_assert(ROWS * NKP * (SYM ? 2 : 1) <= THREADS, "one output item per thread");
+        if (have_prev) {
+            const int per = nT * nK;
+            const int64_t left = N - prev_chunk * SPB;
+            const int nvalid = left < SPB ? (int)left : SPB;              // surfaces of the previous chunk
+            double *__restrict__ out = ratio_out + prev_chunk * (int64_t)(SPB * per);
+            if (SYM) {
+                // item = (row, half-strike k, direct | mirror image)
+                const int row = tid / (2 * NKP);
+                const int rem = tid - row * (2 * NKP);
                 const int k = rem >> 1;
                 const bool mirror = rem & 1;
                 const int col = mirror ? nK - 1 - k : k;
                 const int rs = row / MT;
                 const int t = prev_tile * MT + (row - rs * MT);
-                const int64_t s = prev_chunk * SPB + rs;
-                if (rs < SPB && s < N && t < nT && k < g.nH && (!mirror || col != k)) {
+                if (row < ROWS && rs < nvalid && t < nT && k < g.nH && (!mirror || col != k)) {
                     double v[4];
 #pragma unroll
                     for (int pl = 0; pl < 4; ++pl) {
@@ -413,27 +430,23 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     // planes: 0 = C_1, 1 = C_2, 2 = S_1, 3 = S_2
                     const double p1 = mirror ? v[0] + v[2] : v[0] - v[2];
                     const double p2 = mirror ? v[1] + v[3] : v[1] - v[3];
-                    const double Dq = g.Dq[t], Dr = g.Dr[t], K = g.Kmult[col];
-                    double call = (0.5 * Dq - 0.5 * (K * Dr)) + (p1 - K * p2);
-                    if (!(g.term[t] > 0.0)) call = 0.0;          // expired option: NPV 0
-                    ratio_out[(s * nT + t) * (int64_t)nK + col] = call / g.disc_tau[t];
+                    const double Dq = ecst[1][t], Dr = ecst[2][t], K = ecst[0][col], inv = ecst[3][t];
+                    const double call = (0.5 * Dq - 0.5 * (K * Dr)) + (p1 - K * p2);
+                    out[__mul24(rs, per) + __mul24(t, nK) + col] = inv != 0.0 ? call * inv : 0.0;
                 }
-            }
-        }
-        for (int o = tid; !SYM && have_prev && o < ROWS * NKP; o += THREADS) {
-            const int row = o / NKP;
-            const int col = o - row * NKP;
-            const int rs = row / MT;
-            const int t = prev_tile * MT + (row - rs * MT);
-            const int64_t s = prev_chunk * SPB + rs;
-            if (rs < SPB && s < N && t < nT && col < nK) {
-                double sum = 0.0;
+            } else {
+                const int row = tid / NKP;
+                const int col = tid - row * NKP;
+                const int rs = row / MT;
+                const int t = prev_tile * MT + (row - rs * MT);
+                if (row < ROWS && rs < nvalid && t < nT && col < nK) {
+                    double sum = 0.0;
 #pragma unroll
-                for (int q = 0; q < KS; ++q) sum += xr[(q * ROWS + row) * NKP + col];
-                const double Dq = g.Dq[t], Dr = g.Dr[t], K = g.Kmult[col];
-                double call = (0.5 * Dq - 0.5 * (K * Dr)) + sum;
-                if (!(g.term[t] > 0.0)) call = 0.0;          // expired option: NPV 0
-                ratio_out[(s * nT + t) * (int64_t)nK + col] = call / g.disc_tau[t];
+                    for (int q = 0; q < KS; ++q) sum += xr[(q * ROWS + row) * NKP + col];
+                    const double Dq = ecst[1][t], Dr = ecst[2][t], K = ecst[0][col], inv = ecst[3][t];
+                    const double call = (0.5 * Dq - 0.5 * (K * Dr)) + sum;
+                    out[__mul24(rs, per) + __mul24(t, nK) + col] = inv != 0.0 ? call * inv : 0.0;
+                }
             }
         }
         __syncthreads();          // partial tiles consumed before step G+1 overwrites this buffer
