@@ -258,13 +258,11 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     Model m = {};
     JState st0 = {}, st1 = {};
     Cx ex0 = {}, ex1 = {}, fa0 = {}, fa1 = {}, fb0 = {}, fb1 = {};   // NFAC > 0: running exp(-d T), step factors
-    int64_t prev_chunk = 0;
-    int prev_tile = 0;
+    int64_t prev_chunk = 0, chunk = blockIdx.x;      // advanced with the tile counter: no division per step
+    int prev_tile = 0, tile = 0;
 
     for (int64_t G = 0; G <= total; ++G) {
         const bool have_cur = G < total, have_prev = G > 0;
-        const int64_t chunk = blockIdx.x + (G / ntiles) * (int64_t)gridDim.x;
-        const int tile = (int)(G % ntiles);
         double *xw = lds + (G & 1) * XBUF;                  // written by this step's phase 1
         double *xr = lds + ((G + 1) & 1) * XBUF;            // operand block of the previous step
 
@@ -452,6 +450,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         __syncthreads();          // partial tiles consumed before step G+1 overwrites this buffer
         prev_chunk = chunk;
         prev_tile = tile;
+        if (++tile == ntiles) {
+            tile = 0;
+            chunk += gridDim.x;
+        }
     }
 }
 
