@@ -338,14 +338,16 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             }
         };
         // per-maturity constants (wave-uniform -> scalar registers), fetched one maturity ahead
+        // (term, dd, Dq, Dr are consecutive [nT] arrays of the grid block: one base pointer)
+        const double *__restrict__ mc = g.term;
         int tn = min(tile * MT, nT - 1);
-        double Tn = g.term[tn], ddn = g.dd[tn], Dqn = g.Dq[tn], Drn = g.Dr[tn];
+        double Tn = mc[tn], ddn = mc[nT + tn], Dqn = mc[2 * nT + tn], Drn = mc[3 * nT + tn];
 #pragma unroll 1
         for (int tl = 0; tl < MT; ++tl) {
             const double T = Tn, ddt = ddn, Dq = Dqn, Dr = Drn;
             const int t = tile * MT + tl;
             tn = min(t + 1, nT - 1);
-            Tn = g.term[tn]; ddn = g.dd[tn]; Dqn = g.Dq[tn]; Drn = g.Dr[tn];
+            Tn = mc[tn]; ddn = mc[nT + tn]; Dqn = mc[2 * nT + tn]; Drn = mc[3 * nT + tn];
             // extra days on top of the base step that lead to maturity t (wave-uniform)
             const int extra = NFAC > 1 ? (int)((g.step_sel >> (2 * t)) & 3ull) : 0;
             if (have_cur) {
@@ -407,10 +409,15 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             const int64_t left = N - prev_chunk * SPB;
             const int nvalid = left < SPB ? (int)left : SPB;              // surfaces of the previous chunk
             double *__restrict__ out = ratio_out + prev_chunk * (int64_t)(SPB * per);
+            // The item's indices are re-derived from the thread index at every step: hoisted out
+            // of the loop they would be spilled and come back through scratch loads, here, where
+            // nothing covers their latency.
+            int o = tid;
+            asm volatile("" : "+v"(o));
             if (SYM) {
                 // item = (row, half-strike k, direct | mirror image)
-                const int row = tid / (2 * NKP);
-                const int rem = tid - row * (2 * NKP);
+                const int row = o / (2 * NKP);
+                const int rem = o - row * (2 * NKP);
                 const int k = rem >> 1;
                 const bool mirror = rem & 1;
                 const int col = mirror ? nK - 1 - k : k;
@@ -433,8 +440,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     out[__mul24(rs, per) + __mul24(t, nK) + col] = inv != 0.0 ? call * inv : 0.0;
                 }
             } else {
-                const int row = tid / NKP;
-                const int col = tid - row * NKP;
+                const int row = o / NKP;
+                const int col = o - row * NKP;
                 const int rs = row / MT;
                 const int t = prev_tile * MT + (row - rs * MT);
                 if (row < ROWS && rs < nvalid && t < nT && col < nK) {
