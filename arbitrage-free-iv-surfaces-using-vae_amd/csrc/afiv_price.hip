@@ -340,14 +340,11 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         // per-maturity constants (wave-uniform -> scalar registers), fetched one maturity ahead
         // (term, dd, Dq, Dr are consecutive [nT] arrays of the grid block: one base pointer)
         const double *__restrict__ mc = g.term;
-        int tn = min(tile * MT, nT - 1);
-        double Tn = mc[tn], ddn = mc[nT + tn], Dqn = mc[2 * nT + tn], Drn = mc[3 * nT + tn];
 #pragma unroll 1
         for (int tl = 0; tl < MT; ++tl) {
-            const double T = Tn, ddt = ddn, Dq = Dqn, Dr = Drn;
             const int t = tile * MT + tl;
-            tn = min(t + 1, nT - 1);
-            Tn = mc[tn]; ddn = mc[nT + tn]; Dqn = mc[2 * nT + tn]; Drn = mc[3 * nT + tn];
+            const int tc = min(t, nT - 1);
+            const double T = mc[tc], ddt = mc[nT + tc], Dq = mc[2 * nT + tc], Dr = mc[3 * nT + tc];
             // extra days on top of the base step that lead to maturity t (wave-uniform)
             const int extra = NFAC > 1 ? (int)((g.step_sel >> (2 * t)) & 3ull) : 0;
             if (have_cur) {
