@@ -244,14 +244,11 @@ __device__ __forceinline__ double atan2_tab_f64(double y, double x, const double
     const double h = __builtin_fma(kd, -0x1p-6, t);
     const unsigned j = min((unsigned)__double2loint(shifted), 64u);   // (a NaN quotient must not index past the table)
     const d2 *row = reinterpret_cast<const d2 *>(tab) + 4 * j;
-    // the row is read in two halves so that four, not eight, coefficient registers are live
-    const d2 c45 = row[2], c67 = row[3];
+    const d2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
     double a = c67.y;
     a = __builtin_fma(a, h, c67.x);
     a = __builtin_fma(a, h, c45.y);
     a = __builtin_fma(a, h, c45.x);
-    asm volatile("" : "+v"(a));
-    const d2 c01 = row[0], c23 = row[1];
     a = __builtin_fma(a, h, c23.y);
     a = __builtin_fma(a, h, c23.x);
     a = __builtin_fma(a, h, c01.y);
