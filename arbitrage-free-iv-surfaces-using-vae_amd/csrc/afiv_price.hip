@@ -412,15 +412,20 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             int o = tid;
             asm volatile("" : "+v"(o));
             if (SYM) {
-                // item = (row, half-strike k, direct | mirror image)
-                const int row = o / (2 * NKP);
-                const int rem = o - row * (2 * NKP);
+              if (64 * wave < SPB * MT * 2 * g.nH) {
+                // item = (row, half-strike k, direct | mirror image), numbered densely over the
+                // rows and half-strikes that exist, so that whole waves past the last item skip
+                // the block (the float quotient is exact: o + 1/2 is at least 1/(4 nH) away from a
+                // multiple of 2 nH)
+                const int twoH = 2 * g.nH;
+                const int row = (int)(((float)o + 0.5f) * (1.0f / (float)twoH));
+                const int rem = o - __mul24(row, twoH);
                 const int k = rem >> 1;
                 const bool mirror = rem & 1;
                 const int col = mirror ? nK - 1 - k : k;
                 const int rs = row / MT;
                 const int t = prev_tile * MT + (row - rs * MT);
-                if (row < ROWS && rs < nvalid && t < nT && k < g.nH && (!mirror || col != k)) {
+                if (row < SPB * MT && rs < nvalid && t < nT && (!mirror || col != k)) {
                     double v[4];
 #pragma unroll
                     for (int pl = 0; pl < 4; ++pl) {
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     const double call = (0.5 * Dq - 0.5 * (K * Dr)) + (p1 - K * p2);
                     out[__mul24(rs, per) + __mul24(t, nK) + col] = inv != 0.0 ? call * inv : 0.0;
                 }
+              }
             } else {
                 const int row = o / NKP;
                 const int col = o - row * NKP;
