@@ -67,6 +67,45 @@ def test_atan2_all_quadrants(afiv):
     assert relerr(got, ref).max() <= 3 * EPS
 
 
+def test_table_driven_functions_at_their_bin_edges(afiv):
+    """sincos, log1p and atan2 reduce against tables (pi/32 steps; 128 bins of the mantissa laid out
+    around 1.0; 1/64 steps of the quotient): the points where the bin index changes, where the
+    rounding of the index is a tie, and the neighbourhood of the bins that carry exact entries."""
+    import struct
+    ulps = np.array([-2.0, -1.0, 0.0, 1.0, 2.0])
+    # log1p: u = 1 + f on both sides of every bin edge, over a few binades, and around u = 1
+    edges = [struct.unpack("<d", struct.pack("<Q", (0x3fe5f000 + i * 0x2000) << 32))[0] for i in range(129)]
+    u = np.array([np.nextafter(e, np.inf if d > 0 else -np.inf) if d else e for e in edges for d in (-1, 0, 1)])
+    f = np.concatenate([(u * 2.0 ** k) - 1.0 for k in (-2, -1, 0, 1, 5)] +
+                       [np.array([s * 2.0 ** -e for e in (8, 9, 10, 30, 52, 60, 200)
+                                  for s in (1.0, -1.0, 1 + 2.0 ** -30, -(1 - 2.0 ** -30))])])
+    f = f[f > -1.0]
+    got = run(afiv, "log1p", f)
+    ref = [mp.log1p(mp.mpf(float(v))) for v in f]
+    nz = np.array([r != 0 for r in ref])
+    assert relerr(got[nz], [r for r, k in zip(ref, nz) if k]).max() <= 3 * EPS
+    assert np.all(got[~nz] == 0.0)
+    # atan2: quotients at j/64 and (j + 1/2)/64, a few ulp either side, in every octant
+    tq = np.concatenate([(j / 64.0) * (1 + ulps * EPS) for j in range(1, 65)] +
+                        [((j + 0.5) / 64.0) * (1 + ulps * EPS) for j in range(64)])
+    ys, xs = [], []
+    for sy, sx, swap in ((1, 1, 0), (1, -1, 0), (-1, 1, 0), (-1, -1, 0), (1, 1, 1), (-1, -1, 1)):
+        a, b = (tq, np.ones_like(tq)) if not swap else (np.ones_like(tq), tq)
+        ys.append(sy * a * 3.7); xs.append(sx * b * 3.7)
+    y, x = np.concatenate(ys), np.concatenate(xs)
+    got = run(afiv, "atan2", y, x)
+    ref = [mp.atan2(mp.mpf(float(a)), mp.mpf(float(b))) for a, b in zip(y, x)]
+    assert relerr(got, ref).max() <= 3 * EPS
+    # sincos: multiples and half-multiples of pi/32, near and far
+    m = np.concatenate([np.arange(-200, 201), [10 ** 4, 10 ** 6 + 17, -(10 ** 7) - 3]]).astype(np.float64)
+    xx = np.concatenate([(m * np.pi / 32) * (1 + d * EPS) for d in ulps] +
+                        [((m + 0.5) * np.pi / 32) * (1 + d * EPS) for d in ulps])
+    sn, cs = run(afiv, "sincos", xx)
+    es = np.array([abs(float(mp.mpf(float(a)) - mp.sin(mp.mpf(float(v))))) for a, v in zip(sn, xx)])
+    ec = np.array([abs(float(mp.mpf(float(a)) - mp.cos(mp.mpf(float(v))))) for a, v in zip(cs, xx)])
+    assert es.max() <= 3e-16 and ec.max() <= 3e-16
+
+
 def test_rcp(afiv):
     rng = np.random.default_rng(4)
     x = rng.standard_normal(4000) * 10.0 ** rng.uniform(-100, 100, 4000)
