@@ -37,6 +37,7 @@ SIGNATURES = {
     "afiv_grid_create": (c_int, [ctypes.POINTER(c_void_p), _dp, c_int, _dp, c_int, c_double, c_double,
                                  c_int, c_i64]),
     "afiv_grid_destroy": (c_int, [c_void_p]),
+    "afiv_grid_traits": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "afiv_price": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "afiv_implied_vol": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p]),
     "afiv_arb_check": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p,

@@ -67,6 +67,14 @@ class Grid:
                 int(workspace_surfaces))
         _lib.check(rc, "afiv_grid_create")
 
+    @property
+    def traits(self) -> dict:
+        """{"half_strike": bool, "stepped": 0 | 1 | 2}: the pricing shortcuts this lattice takes
+        (see afiv_grid_traits)."""
+        hs, st = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().afiv_grid_traits(self._h, ctypes.byref(hs), ctypes.byref(st)), "afiv_grid_traits")
+        return {"half_strike": bool(hs.value), "stepped": st.value}
+
     def close(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:

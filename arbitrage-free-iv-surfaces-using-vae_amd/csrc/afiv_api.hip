@@ -55,13 +55,18 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     // Host-side constants use the host libm so that discount factors, forwards and strikes are
     // the very doubles NumPy produces in the Python reference.
     const size_t n_point = (size_t)4 * nT * nK;     // device-written table, kept 32-byte aligned
-    // strikes symmetric about log K = 0 (to a few ulp): half of them carry the contraction
+    // strikes symmetric about their midpoint (to a few ulp) -- any linspace(a, b, n) is: half of them
+    // carry the contraction.  A midpoint other than 0 is a phase x_n c of the integrand, folded into
+    // the per-maturity drift term below.
     const int nH = (nK + 1) / 2, nHpad = (nH + 15) / 16 * 16;
     bool sym = nK >= 4;
     double scale = 0.0;
     for (int k = 0; k < nK; ++k) scale = std::fmax(scale, std::fabs(logm[k]));
+    double center = 0.5 * (logm[0] + logm[nK - 1]);
+    if (!(std::fabs(center) > 8.9e-16 * scale)) center = 0.0;
     for (int k = 0; k < nK && sym; ++k)
-        if (!(std::fabs(logm[k] + logm[nK - 1 - k]) <= 8.9e-16 * scale)) sym = false;
+        if (!(std::fabs((logm[k] - center) + (logm[nK - 1 - k] - center)) <= 8.9e-16 * scale)) sym = false;
+    if (!sym) center = 0.0;
     const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
     const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
     const size_t n_order = ((size_t)nT * nK * sizeof(unsigned short) + 31) / 32 * 4;   // in doubles, 32-byte multiple
@@ -77,7 +82,9 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
         p_term[t] = trunc_days ? (double)((long)(tau[t] * 365.0)) / 365.0 : tau[t];
         p_Dr[t] = 1.0 / std::exp(r * p_term[t]);
         p_Dq[t] = 1.0 / std::exp(q * p_term[t]);
-        p_dd[t] = std::log(1.0) - std::log(p_Dr[t] / p_Dq[t]);
+        // (minus the strike grid's midpoint when the half-strike contraction is used: the pricing
+        // kernel is this array's only reader)
+        p_dd[t] = std::log(1.0) - std::log(p_Dr[t] / p_Dq[t]) - center;
         p_disc[t] = std::exp(-r * tau[t]);
         p_fwd[t] = std::exp((r - q) * tau[t]);
         p_dq[t] = std::exp(-q * tau[t]);
@@ -106,7 +113,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
 
     if (sym) {
         for (int k = 0; k < nH; ++k) {
-            const double sx = std::log(p_K[k]);
+            const double sx = std::log(p_K[k]) - center;
             for (int n = 0; n < AFIV_NQ_NODES; ++n) {
                 const double ang = AFIV_LAG_X[n] * sx;
                 p_sym[(size_t)n * nHpad + k] = std::cos(ang);
@@ -194,6 +201,14 @@ int afiv_grid_destroy(afiv_grid *g)
     if (g->workspace) (void)hipFree(g->workspace);
     if (g->block) (void)hipFree(g->block);
     delete g;
+    return AFIV_OK;
+}
+
+int afiv_grid_traits(const afiv_grid *g, int *half_strike, int *stepped)
+{
+    if (!g) return AFIV_E_NULL;
+    if (half_strike) *half_strike = g->v.sym;
+    if (stepped) *stepped = g->v.step_count;
     return AFIV_OK;
 }
 

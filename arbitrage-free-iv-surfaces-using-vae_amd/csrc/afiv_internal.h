@@ -16,7 +16,7 @@ struct GridView {
     double r, q;
     const double *tau;        // [nT] maturities as given
     const double *term;       // [nT] year fraction actually priced (floor(365 tau)/365 or tau)
-    const double *dd;         // [nT] -log(Dr/Dq)
+    const double *dd;         // [nT] -log(Dr/Dq) (sym: minus the strike grid's midpoint)
     const double *Dq;         // [nT] 1/exp(q*term)
     const double *Dr;         // [nT] 1/exp(r*term)
     const double *disc_tau;   // [nT] exp(-r*tau)
@@ -25,8 +25,9 @@ struct GridView {
     const double *logm;       // [nK]
     const double *Kmult;      // [nK] exp(logm)
     const double *tab;        // [AFIV_KDIM][nKpad] strike tables, see afiv_price.hip
-    // Symmetric strike grids (log K_k = -log K_{nK-1-k}): sym = 1, nH = (nK + 1)/2 strikes carry
-    // the contraction, nHpad = nH rounded up to 16, tab_sym = [2][144][nHpad]: cos, sin of x_n log K_k.
+    // Strike grids symmetric about their midpoint c (log K_k - c = -(log K_{nK-1-k} - c)): sym = 1,
+    // nH = (nK + 1)/2 strikes carry the contraction, nHpad = nH rounded up to 16,
+    // tab_sym = [2][144][nHpad]: cos, sin of x_n (log K_k - c).
     int sym, nH, nHpad;
     const double *tab_sym;
     // Regular term structures (afiv_price.hip, NFAC): step_count = 0 (none), 1 (successive year

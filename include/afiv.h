@@ -70,6 +70,15 @@ int afiv_grid_create(afiv_grid **out, const double *logm_host, int nK, const dou
                      int nT, double r, double q, int trunc_days, int64_t workspace_surfaces);
 int afiv_grid_destroy(afiv_grid *g);
 
+/* Which of the pricing kernel's shortcuts the lattice qualifies for (no counterpart in the
+ * reference; for tests and for callers who want to know why one grid prices faster than another).
+ * half_strike = 1: the strikes are symmetric about their midpoint (any linspace(a, b, n), n >= 4),
+ * so half of them carry the matrix work.  stepped = 0, 1, 2: whole-day maturities a constant
+ * number of days apart (1), or a base step plus 0..3 days (2), advance exp(-d T) by complex
+ * multiplications instead of an exp and a sincos per maturity (needs trunc_days = 1); 0: neither.
+ * Either pointer may be NULL.  Results do not depend on these beyond rounding. */
+int afiv_grid_traits(const afiv_grid *g, int *half_strike, int *stepped);
+
 /* ---- pricing: replaces HestonModelQL.price_ratio (heston_model_ql.py:151-179) evaluated over
  * the whole grid, i.e. QuantLib AnalyticHestonEngine(model) (:87) per option.
  * params: device [N,5] doubles (kappa, theta, sigma_v, rho, v0); ratio_out: device [N,nT,nK]. */

@@ -20,7 +20,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
-    for s in ("afiv_version", "afiv_grid_create", "afiv_grid_destroy", "afiv_price",
+    for s in ("afiv_version", "afiv_grid_create", "afiv_grid_destroy", "afiv_grid_traits", "afiv_price",
               "afiv_implied_vol", "afiv_arb_check", "afiv_implied_vol_checked", "afiv_surface", "afiv_decoder_create",
               "afiv_decoder_destroy", "afiv_decode", "afiv_arbitrage_penalty",
               "afiv_stage1_objective", "afiv_error_string", "afiv_debug_math"):

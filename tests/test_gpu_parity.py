@@ -388,19 +388,20 @@ def test_price_against_50_digit_quadrature_at_small_vol_of_vol(afiv, golden_dir)
     assert np.abs(orc - ref).max() > 100 * np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("days", [
-    [30, 60, 90, 120, 150, 180],                      # one increment: one step factor
-    [30, 67, 104, 141, 177, 214, 250, 288, 325],      # 36..38 days: base step plus one-day factors
-    [10, 13, 16, 20, 23, 26, 29, 33],                 # base 3 days, up to 1 extra
-    [30, 60, 91, 182, 273, 365, 547, 730],            # irregular: every maturity evaluated directly
+@pytest.mark.parametrize("days,stepped", [
+    ([30, 60, 90, 120, 150, 180], 1),                      # one increment: one step factor
+    ([30, 67, 104, 141, 177, 214, 250, 288, 325], 2),      # 36..38 days: base step plus one-day factors
+    ([10, 13, 16, 20, 23, 26, 29, 33], 2),                 # base 3 days, up to 1 extra
+    ([30, 60, 91, 182, 273, 365, 547, 730], 0),            # irregular: every maturity evaluated directly
 ])
-def test_price_regular_and_irregular_term_structures(afiv, days):
+def test_price_regular_and_irregular_term_structures(afiv, days, stepped):
     """Whole-day year fractions take the stepped evaluation of exp(-d T) when the increments allow
     it; every mode meets the same bound against the oracle."""
     tau = (np.array(days) + 0.5) / 365.0              # truncates to `days` (heston_model_ql.py:131)
     assert [int(t * 365.0) for t in tau] == days
     logm = np.linspace(-0.15, 0.15, 7)
     grid = afiv.Grid(logm, tau, R, Q)
+    assert grid.traits["stepped"] == stepped
     p = sample_params(96, 31)
     got = grid.price(dev(p)).cpu().numpy()
     ref = oracle.price_ratio_grid(p, logm, tau, R, Q)
@@ -445,18 +446,31 @@ def test_wave_per_surface_mode_equals_workgroup_per_surface_mode(afiv, grid821, 
     assert bool(torch.isnan(iv_big[11]).all())
 
 
-@pytest.mark.parametrize("logm", [
-    np.linspace(-0.3, 0.1, 7),            # asymmetric: general contraction, one column tile
-    np.linspace(-0.25, 0.15, 21),         # asymmetric, two column tiles
-    np.linspace(-0.2, 0.3, 50),           # asymmetric, four column tiles
-    np.linspace(-0.2, 0.2, 4),            # symmetric, smallest grid that takes the half-strike path
-    np.linspace(-0.2, 0.2, 5),            # symmetric, odd (the middle strike is its own mirror image)
-    np.linspace(-0.2, 0.2, 33),           # symmetric, 17 half-strikes: two column tiles
-    np.linspace(-0.3, 0.3, 64),           # symmetric, largest
-], ids=["asym7", "asym21", "asym50", "sym4", "sym5", "sym33", "sym64"])
-def test_price_symmetric_and_asymmetric_strike_grids(afiv, logm):
+def _uneven(lo, hi, n):
+    """n strikes on [lo, hi] with unequal spacing: no midpoint symmetry, so the general contraction."""
+    u = np.linspace(0.0, 1.0, n)
+    return lo + (hi - lo) * (0.7 * u + 0.3 * u * u)
+
+
+@pytest.mark.parametrize("logm,half", [
+    (_uneven(-0.3, 0.1, 7), False),             # general contraction, one column tile
+    (_uneven(-0.25, 0.15, 21), False),          # general, two column tiles
+    (_uneven(-0.2, 0.3, 50), False),            # general, four column tiles
+    (np.linspace(-0.2, 0.2, 4), True),          # symmetric, smallest grid that takes the half-strike path
+    (np.linspace(-0.2, 0.2, 5), True),          # symmetric, odd (the middle strike is its own mirror image)
+    (np.linspace(-0.2, 0.2, 33), True),         # symmetric, 17 half-strikes: two column tiles
+    (np.linspace(-0.3, 0.3, 64), True),         # symmetric, largest
+    (np.linspace(-0.3, 0.1, 7), True),          # symmetric about -0.1: midpoint folded into the drift term
+    (np.linspace(-0.25, 0.15, 21), True),       # symmetric about -0.05
+    (np.linspace(-0.2, 0.3, 50), True),         # symmetric about +0.05
+    (np.linspace(0.05, 0.6, 33), True),         # all strikes on one side of the money
+    (np.linspace(-0.2, 0.2, 3), False),         # fewer than four strikes: general path
+], ids=["uneven7", "uneven21", "uneven50", "sym4", "sym5", "sym33", "sym64", "off7", "off21", "off50", "oneside33",
+        "three"])
+def test_price_symmetric_and_asymmetric_strike_grids(afiv, logm, half):
     tau = np.array([0.05, 0.3, 1.0, 2.5])
     grid = afiv.Grid(logm, tau, R, Q)
+    assert grid.traits["half_strike"] == half
     p = sample_params(80, 51)
     got = grid.price(dev(p)).cpu().numpy()
     ref = oracle.price_ratio_grid(p, logm, tau, R, Q)
@@ -464,6 +478,21 @@ def test_price_symmetric_and_asymmetric_strike_grids(afiv, logm):
     assert np.all(err <= 1.0), f"max excess {err.max():.3g}"
     big = p[:, 2] >= 0.06
     assert np.all(np.abs(got - ref)[big] <= price_tol(ref[big]))
+
+
+def test_off_centre_half_strike_contraction_agrees_with_general_contraction(afiv):
+    """A grid symmetric about -0.05 and the same grid with one strike moved by 1e-13 (general path)
+    price every other strike identically to rounding."""
+    logm = np.linspace(-0.25, 0.15, 21)
+    moved = logm.copy()
+    moved[5] += 1e-13
+    tau = np.array([0.1, 0.5, 1.0, 2.0])
+    ga, gb = afiv.Grid(logm, tau, R, Q), afiv.Grid(moved, tau, R, Q)
+    assert ga.traits["half_strike"] and not gb.traits["half_strike"]
+    p = dev(sample_params(64, 53))
+    a, b = ga.price(p).cpu().numpy(), gb.price(p).cpu().numpy()
+    keep = np.arange(21) != 5
+    assert np.abs(a[:, :, keep] - b[:, :, keep]).max() <= 1e-14
 
 
 def test_half_strike_contraction_agrees_with_general_contraction(afiv):
