@@ -126,8 +126,8 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
             s.a = {t1.r - s.d.r, t1.i - s.d.i};
             s.sum = cmul(su, crcp(s.a));
         }
-        const Cx p = cmul(s.a, crcp(s.sum));
-        s.pq = cmul(p, crcp(Cx{1.0 - p.r, -p.i}));
+        // p / (1 - p) with p = a / sum: 1 - p = (sum - a) / sum = 2 d / sum, so the quotient is a / (2 d)
+        s.pq = cmul(s.a, crcp(Cx{2.0 * s.d.r, 2.0 * s.d.i}));
     } else {
         // vol-of-vol <= 1e-5 series, as the reference engine switches: td = phi/(2 t1) u ;
         // p = td sigma^2/(t1+d)
