@@ -58,7 +58,8 @@ def price_bad(got, ref, p, tau):
     NaN, and either inverts to a NaN vol."""
     noise = 32 * np.finfo(float).eps / p[:, 2, None, None] ** 2 * \
         np.maximum(1.0, (p[:, 0] * p[:, 1])[:, None, None] * np.abs(tau)[None, :, None])
-    tol = price_tol(ref) + noise + 1e-4 * np.abs(ref) * (np.abs(ref) > 10.0)
+    series = (p[:, 2] <= 1e-5)[:, None, None]                  # the reference's series form: 5-7 digits
+    tol = price_tol(ref) + noise + 1e-4 * np.abs(ref) * ((np.abs(ref) > 10.0) | series)
     wild = lambda a: ~np.isfinite(a) | (np.abs(a) > 1e300)     # overflowed, or one doubling away from it
     with np.errstate(invalid="ignore"):
         return ~(np.abs(got - ref) <= tol) & ~(wild(got) & wild(ref))
