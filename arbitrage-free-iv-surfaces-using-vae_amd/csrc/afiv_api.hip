@@ -191,6 +191,17 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
             v.step_sel = sel;
         }
     }
+    if (!trunc_days && nT >= 4 && nT <= 32) {
+        // exact year fractions, evenly spaced to a few ulp (linspace): one step factor
+        const double step = (tau[nT - 1] - tau[0]) / (double)(nT - 1);
+        bool ok = tau[0] >= 0.0 && step > 0.0;
+        for (int t = 1; t < nT && ok; ++t)
+            if (!(std::fabs((tau[t] - tau[t - 1]) - step) <= 8.9e-16 * std::fabs(tau[nT - 1]))) ok = false;
+        if (ok) {
+            v.step_count = 1;
+            v.step_dt[0] = step;
+        }
+    }
     *out = g;
     return AFIV_OK;
 }

@@ -75,7 +75,8 @@ int afiv_grid_destroy(afiv_grid *g);
  * half_strike = 1: the strikes are symmetric about their midpoint (any linspace(a, b, n), n >= 4),
  * so half of them carry the matrix work.  stepped = 0, 1, 2: whole-day maturities a constant
  * number of days apart (1), or a base step plus 0..3 days (2), advance exp(-d T) by complex
- * multiplications instead of an exp and a sincos per maturity (needs trunc_days = 1); 0: neither.
+ * multiplications instead of an exp and a sincos per maturity; with trunc_days = 0, evenly spaced
+ * year fractions (a linspace) do the same (1); 0: neither.  4 to 32 maturities either way.
  * Either pointer may be NULL.  Results do not depend on these beyond rounding. */
 int afiv_grid_traits(const afiv_grid *g, int *half_strike, int *stepped);
 

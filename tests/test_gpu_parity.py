@@ -427,6 +427,26 @@ def test_stepped_exponential_agrees_with_direct_evaluation(afiv):
     assert worst <= 2e-13, worst
 
 
+def test_stepped_exponential_on_evenly_spaced_exact_year_fractions(afiv):
+    """Without day truncation an evenly spaced maturity grid takes one step factor; it meets the
+    oracle's bound and agrees with the direct evaluation (3-maturity sub-grids) to rounding."""
+    tau = np.linspace(0.1, 2.0, 20)
+    logm = np.linspace(-0.2, 0.2, 9)
+    grid = afiv.Grid(logm, tau, R, Q, trunc_days=False)
+    assert grid.traits["stepped"] == 1
+    assert afiv.Grid(logm, tau ** 1.1, R, Q, trunc_days=False).traits["stepped"] == 0
+    p = sample_params(64, 43)
+    full = grid.price(dev(p)).cpu().numpy()
+    ref = oracle.price_ratio_grid(p, logm, tau, R, Q, False)
+    assert np.all(np.abs(full - ref) <= price_tol(ref, p))
+    worst = 0.0
+    for lo in (0, 9, 17):
+        sub = afiv.Grid(logm, tau[lo:lo + 3], R, Q, trunc_days=False)
+        assert sub.traits["stepped"] == 0
+        worst = max(worst, float(np.abs(sub.price(dev(p)).cpu().numpy() - full[:, lo:lo + 3]).max()))
+    assert worst <= 2e-13, worst
+
+
 @pytest.mark.parametrize("variant", ["A", "B"])
 def test_wave_per_surface_mode_equals_workgroup_per_surface_mode(afiv, grid821, variant):
     """Batches of 2048 surfaces or more take the wave-per-surface schedule, smaller ones the
