@@ -26,6 +26,10 @@
 // fragments stream from the L2-resident table through raw buffer loads (one offset register
 // instead of a 64-bit address pair per fragment), two batches in flight; partial tiles are
 // reduced through LDS in a fixed order (bitwise reproducible results).
+// The elementary functions of phase 1 (afiv_math.h) reduce their arguments against three small
+// tables that live in LDS beside the operand buffers; the per-strike and per-maturity constants
+// of the epilogue are staged there too, because the epilogue runs between two workgroup barriers
+// where no other wave's work covers a global load.
 #include "afiv_internal.h"
 #include "afiv_math.h"
 #include "laguerre144.inc"
