@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 
-VARIANTS = {"A": 0, "B": 1, 0: 0, 1: 1}
+VARIANTS = {"A": 0, "B": 1, "A_BRENT": 2, 0: 0, 1: 1, 2: 2}
 
 # status bits of the flag word (column 3 of the [N,4] flags tensor)
 STATUS_ARB_FREE = 1        # static == 0 and calendar == 0 on a valid surface

@@ -54,7 +54,6 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
 
     // Host-side constants use the host libm so that discount factors, forwards and strikes are
     // the very doubles NumPy produces in the Python reference.
-    const size_t n_point = (size_t)4 * nT * nK;     // device-written table, kept 32-byte aligned
     // strikes symmetric about their midpoint (to a few ulp) -- any linspace(a, b, n) is: half of them
     // carry the contraction.  A midpoint other than 0 is a phase x_n c of the integrand, folded into
     // the per-maturity drift term below.
@@ -70,7 +69,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
     const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
     const size_t n_order = ((size_t)nT * nK * sizeof(unsigned short) + 31) / 32 * 4;   // in doubles, 32-byte multiple
-    const size_t nd = n_const + n_point + n_order;
+    const size_t nd = n_const + n_order;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
            *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
@@ -134,7 +133,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
             }
         std::stable_sort(idx.begin(), idx.end(),
                          [&](unsigned short a, unsigned short b) { return score[a] > score[b]; });
-        std::memcpy(h.data() + n_const + n_point, idx.data(), per * sizeof(unsigned short));
+        std::memcpy(h.data() + n_const, idx.data(), per * sizeof(unsigned short));
     }
 
     afiv_grid *g = new (std::nothrow) afiv_grid();
@@ -164,8 +163,7 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     v.nH = nH;
     v.nHpad = nHpad;
     v.tab_sym = v.tab + (size_t)AFIV_KDIM * nKpad;
-    v.point = dev + n_const;
-    v.order = reinterpret_cast<const unsigned short *>(dev + n_const + n_point);
+    v.order = reinterpret_cast<const unsigned short *>(dev + n_const);
     // whole-day year fractions with at most two distinct increments: see price_kernel's NFAC
     v.step_count = 0;
     v.step_dt[0] = v.step_dt[1] = 0.0;
@@ -239,7 +237,7 @@ int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double 
     int rc = check_grid(g);
     if (rc) return rc;
     if (N < 0) return AFIV_E_SHAPE;
-    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (variant < AFIV_VARIANT_A || variant > AFIV_VARIANT_A_BRENT) return AFIV_E_ARG;
     if (N == 0) return AFIV_OK;
     if (!ratio || !iv_out) return AFIV_E_NULL;
     return afiv_launch_implied_vol(g->v, ratio, N, spot, variant, iv_out, as_stream(stream));
@@ -263,7 +261,7 @@ int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N,
     int rc = check_grid(g);
     if (rc) return rc;
     if (N < 0) return AFIV_E_SHAPE;
-    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (variant < AFIV_VARIANT_A || variant > AFIV_VARIANT_A_BRENT) return AFIV_E_ARG;
     if (N == 0) return AFIV_OK;
     if (!ratio || !iv_out || !flags_out) return AFIV_E_NULL;
     return afiv_launch_surface_iv(g->v, ratio, N, spot, variant, iv_out, flags_out, as_stream(stream));
@@ -275,7 +273,7 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
     int rc = check_grid(g);
     if (rc) return rc;
     if (N < 0) return AFIV_E_SHAPE;
-    if (variant != AFIV_VARIANT_A && variant != AFIV_VARIANT_B) return AFIV_E_ARG;
+    if (variant < AFIV_VARIANT_A || variant > AFIV_VARIANT_A_BRENT) return AFIV_E_ARG;
     if (N == 0) return AFIV_OK;
     if (!params || !iv_out || !flags_out) return AFIV_E_NULL;
     hipStream_t s = as_stream(stream);

@@ -40,10 +40,6 @@ struct GridView {
                                    // in which the implied-vol kernel hands points to lanes (points far
                                    // from the money need the most root-finder iterations; served first,
                                    // they leave a short tail)
-    double *point;            // [nT*nK][4] per-call table of the implied-vol kernel (log F/K and the
-                              // Black-Scholes values at the bracket ends for the call's spot);
-                              // rewritten by every implied-vol call, so calls on one grid must
-                              // not overlap
 };
 
 struct afiv_grid {
@@ -88,6 +84,8 @@ int afiv_launch_debug_math(int op, const double *x, const double *y, int64_t n, 
 int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t s);
 int afiv_launch_surface_iv(const GridView &g, const double *ratio, int64_t N, double spot, int variant,
                            double *iv_out, int32_t *flags, hipStream_t s);
+int afiv_launch_fast_iv(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
+                        int32_t *flags, hipStream_t s);
 int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
                          hipStream_t s);
 int afiv_launch_density_wasserstein(const GridView &g, const double *model_ratio, int64_t C,

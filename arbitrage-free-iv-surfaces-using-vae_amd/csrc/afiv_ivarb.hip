@@ -10,209 +10,17 @@
 //                 variant B's objective is not monotone and only the same iteration path
 //                 lands on the same root.
 //   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
-#include "afiv_internal.h"
-#include "afiv_math.h"
-#include "erfcx_table.inc"
+#include "afiv_bs.h"
 
 namespace {
-
-// Normal CDF through one scaled complementary error function: N(a) = erfc(-a/sqrt 2)/2 with
-// erfc(u) = exp(-u^2) erfcx(u), erfcx from a 64-segment degree-8 table in y = 1/(1+u) (see
-// tools/gen_erfcx_table.py; 1.5 ulp).  One code path for every lane -- the C library's erf/erfc
-// pick one of five ranges per argument, which a wave executes back to back when its lanes
-// disagree.  The table lives in LDS (ERFCX_LDS doubles, filled by load_erfcx_table).
-__constant__ double c_erfcx[AFIV_ERFCX_NSEG * AFIV_ERFCX_NCOEF] = {AFIV_ERFCX_TABLE};
-constexpr int ERFCX_ROW = 10;                       // 9 coefficients padded to 80 B rows
-constexpr int ERFCX_LDS = AFIV_ERFCX_NSEG * ERFCX_ROW;
-static_assert(AFIV_ERFCX_NCOEF == 9 && AFIV_ERFCX_NSEG == 64, "erfcx table shape");
-
-__device__ __forceinline__ void load_erfcx_table(double *lds_tab)
-{
-    for (int i = threadIdx.x; i < ERFCX_LDS; i += blockDim.x) {
-        const int seg = i / ERFCX_ROW, j = i - seg * ERFCX_ROW;
-        lds_tab[i] = j < AFIV_ERFCX_NCOEF ? c_erfcx[seg * AFIV_ERFCX_NCOEF + j] : 0.0;
-    }
-}
-
-template <bool NANSAFE = true>
-__device__ __forceinline__ double ndtr_dev(double a, const double *__restrict__ tab)
-{
-    const double sqrth = 7.07106781186547524401E-1;
-    const double x = a * sqrth;
-    const double u = fmin(fabs(x), 40.0);           // erfc(40) = 0 in double; also maps NaN to a finite dummy
-    const double t = 64.0 * afivm::rcp_f64(1.0 + u);
-    const double tc = fmin(t, 0x1.fffffffffffffp5);      // t = 64 (u = 0) belongs to the last segment
-    const int seg = (int)tc;
-    const double f = __builtin_amdgcn_fract(tc) - 0.5;
-    const double *c = tab + seg * ERFCX_ROW;
-    double p = c[8];
-    p = fma(p, f, c[7]);
-    p = fma(p, f, c[6]);
-    p = fma(p, f, c[5]);
-    p = fma(p, f, c[4]);
-    p = fma(p, f, c[3]);
-    p = fma(p, f, c[2]);
-    p = fma(p, f, c[1]);
-    p = fma(p, f, c[0]);
-    const double s = u * u;
-    const double lo = fma(u, u, -s);                // exact low part of the square
-    double e = NANSAFE ? afivm::exp_f64<false>(-s) : afivm::exp_core_f64<false>(-s);   // s <= 1600
-    e = fma(-e, lo, e);
-    const double h = 0.5 * e * p;                   // erfc(|x|)/2
-    const double r = x > 0 ? 1.0 - h : h;
-    return NANSAFE && x != x ? x : r;               // NaN in, NaN out (callers that never pass NaN opt out)
-}
-
-// Per-point constants of the Black-Scholes objective.
-struct BsPoint {
-    double lnFK;      // log(F/K)                       (variant A)
-    double F, K;      // spot*exp((r-q)tau), spot*exp(logm)
-    double disc;      // exp(-r tau)
-    double sdq;       // spot*exp(-q tau)               (variant B)
-    double kdr;       // K*exp(-r tau)                  (variant B)
-    double logm, rq;  // logm, r - q                    (variant B)
-    double tau, sqrt_tau;
-    double target;    // heston price
-    double ratio;     // exp(-d2^2/2) / exp(-d1^2/2): F/K (variant A), exp(logm + (r-q) tau) (variant B)
-};
-
-// n / d through the hardware reciprocal, two Newton steps and one residual correction: the
-// correctly rounded quotient in all but rare last-bit cases, at half the cost of the IEEE
-// expansion.  d = 0 gives NaN where IEEE gives inf or NaN; every use below only compares the
-// result with "<", which is false for both.
-__device__ __forceinline__ double fdivq(double n, double d)
-{
-    const double r = afivm::rcp_f64(d);
-    const double q = n * r;
-    const double e = __builtin_fma(-d, q, n);
-    return __builtin_fma(e, r, q);
-}
-
-typedef double d2v __attribute__((ext_vector_type(2)));
-
-// Segment and local coordinate of erfcx's table for t = 64/(1 + u) (see ndtr_dev).
-__device__ __forceinline__ const d2v *erfcx_row(double t, const double *__restrict__ tab, double *f)
-{
-    const double tc = fmin(t, 0x1.fffffffffffffp5);      // t = 64 (u = 0) belongs to the last segment
-    const int seg = (int)tc;
-    *f = __builtin_amdgcn_fract(tc) - 0.5;
-    // 24-bit multiply: full rate, where a 32-bit v_mul_lo_u32 runs at a quarter of it
-    return reinterpret_cast<const d2v *>(tab + __mul24(seg, ERFCX_ROW));   // rows are 80 bytes: 16-byte aligned
-}
-
-__device__ __forceinline__ double erfcx_horner(d2v q0, d2v q1, d2v q2, d2v q3, double q4, double f)
-{
-    double p = q4;
-    p = fma(p, f, q3.y);
-    p = fma(p, f, q3.x);
-    p = fma(p, f, q2.y);
-    p = fma(p, f, q2.x);
-    p = fma(p, f, q1.y);
-    p = fma(p, f, q1.x);
-    p = fma(p, f, q0.y);
-    return fma(p, f, q0.x);
-}
-
-// The root finder's objective (without the target): the Black-Scholes value at a vol from the
-// bracket (finite, > 0: no NaN handling, no IEEE special cases in the quotient).  Both normal
-// CDFs share ONE exponential: exp(-d2^2/2) = exp(-d1^2/2) c.ratio, the identity
-// F phi(d1) = K phi(d2) of the formula itself, so N(d2) costs its erfcx polynomial only.  The
-// ten table reads of the two polynomials are issued together, ahead of the exponential, so that
-// their LDS latency is paid once and under that arithmetic (left to the compiler they are sunk
-// next to their uses, one wait per coefficient pair).
-template <int VARIANT>
-__device__ __forceinline__ double bs_objective(const BsPoint &c, double iv, const double *__restrict__ tab,
-                                               const afivm::ExpCoef &ec)
-{
-    const double sqrth = 7.07106781186547524401E-1;
-    double num;
-    if (VARIANT == AFIV_VARIANT_A) num = c.lnFK + 0.5 * (iv * iv) * c.tau;
-    else num = c.logm + (c.rq + 0.5 * (iv * iv)) * c.tau;
-    const double den = iv * c.sqrt_tau;
-    const double d1 = fdivq(num, den);
-    const double d2 = d1 - den;
-    const double x1 = d1 * sqrth, x2 = d2 * sqrth;
-    const double u1 = fabs(x1), u2 = fabs(x2);
-    // both table coordinates from one reciprocal: 64/(1+u1) = 64 (1+u2) / ((1+u1)(1+u2))
-    const double w1 = 1.0 + u1, w2 = 1.0 + u2;
-    const double r64 = 64.0 * afivm::rcp_f64(w1 * w2);
-    double f1, f2;
-    const d2v *r1 = erfcx_row(r64 * w2, tab, &f1);
-    const d2v *r2 = erfcx_row(r64 * w1, tab, &f2);
-    const d2v a0 = r1[0], a1 = r1[1], a2 = r1[2], a3 = r1[3];
-    const double a4 = reinterpret_cast<const double *>(r1)[8];
-    const d2v b0 = r2[0], b1 = r2[1], b2 = r2[2], b3 = r2[3];
-    const double b4 = reinterpret_cast<const double *>(r2)[8];
-    __builtin_amdgcn_sched_barrier(0);
-    const double s = u1 * u1;
-    const double lo = fma(u1, u1, -s);              // exact low part of the square
-    double e = afivm::exp_core_f64(-s, ec);
-    e = 0.5 * fma(-e, lo, e);                       // exp(-u1^2) / 2
-    const double p1 = erfcx_horner(a0, a1, a2, a3, a4, f1);
-    const double p2 = erfcx_horner(b0, b1, b2, b3, b4, f2);
-    const double h1 = e * p1, h2 = (e * c.ratio) * p2;
-    const double n1 = x1 > 0 ? 1.0 - h1 : h1;
-    const double n2 = x2 > 0 ? 1.0 - h2 : h2;
-    // The two products are rounded separately, as NumPy rounds them (this unit is compiled without
-    // FMA contraction): deep in the money the option's time value is a 1e-10 remainder of that
-    // difference, and a fused multiply-add there moves the root by up to 1e-2 in vol.
-    if (VARIANT == AFIV_VARIANT_A) return c.disc * (c.F * n1 - c.K * n2);
-    return c.sdq * n1 - c.kdr * n2;
-}
-
-// FAST: vols come from a root finder's bracket (finite, > 0), so the normal CDF needs no NaN
-// passthrough and the quotient no IEEE special cases.
-template <int VARIANT, bool FAST = false>
-__device__ __forceinline__ double bs_price(const BsPoint &c, double iv, const double *__restrict__ tab)
-{
-    if (VARIANT == AFIV_VARIANT_A) {
-        const double num = c.lnFK + 0.5 * (iv * iv) * c.tau, den = iv * c.sqrt_tau;
-        const double d1 = FAST ? fdivq(num, den) : num / den;
-        const double d2 = d1 - iv * c.sqrt_tau;
-        return c.disc * (c.F * ndtr_dev<!FAST>(d1, tab) - c.K * ndtr_dev<!FAST>(d2, tab));
-    } else {
-        if (iv <= 0 || c.tau <= 0) return 1e10;
-        const double num = c.logm + (c.rq + 0.5 * (iv * iv)) * c.tau, den = iv * c.sqrt_tau;
-        const double d1 = FAST ? fdivq(num, den) : num / den;
-        const double d2 = d1 - iv * c.sqrt_tau;
-        return c.sdq * ndtr_dev<!FAST>(d1, tab) - c.kdr * ndtr_dev<!FAST>(d2, tab);
-    }
-}
-
-__device__ __forceinline__ BsPoint make_point(const GridView &g, int t, int k, double spot, int variant)
-{
-    BsPoint c;
-    c.tau = g.tau[t];
-    c.sqrt_tau = sqrt(c.tau);
-    c.disc = g.disc_tau[t];
-    c.K = spot * g.Kmult[k];
-    c.F = spot * g.fwd_mult[t];
-    c.lnFK = log(c.F / c.K);
-    c.sdq = spot * g.dq_tau[t];
-    c.kdr = c.K * c.disc;
-    c.logm = g.logm[k];
-    c.rq = g.r - g.q;
-    c.target = 0.0;
-    c.ratio = variant == AFIV_VARIANT_A ? c.F / c.K : g.Kmult[k] * g.fwd_mult[t];
-    return c;
-}
+using namespace afivbs;
 
 // One workgroup per surface.
 constexpr int ARB_THREADS = 256;
 #ifndef AFIV_IV_REFILL_LANES
 #define AFIV_IV_REFILL_LANES 8            // idle lanes of a wave that trigger a refill
 #endif
-#ifndef AFIV_IV_THREADS
-#define AFIV_IV_THREADS 512               // fused kernel, wave-per-surface mode: 8 surfaces in flight per workgroup
-#endif
 constexpr int MAX_PTS = AFIV_MAX_STRIKES * AFIV_MAX_MATURITIES;
-
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
 
 template <int BSFORM>
 __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const double *__restrict__ iv,
@@ -310,7 +118,9 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
 // deep in-the-money strikes first) inside the same trip, between the two halves of Brent's loop
 // body, so no lane ever idles through an evaluation while the queue has points.  The objective
 // values at the two bracket ends depend on the grid point and the spot only (minus the target):
-// a small kernel tabulates them once per call, which saves two of the ~12.7 evaluations per point.
+// every workgroup tabulates them in LDS before its first surface (two evaluations per lattice point,
+// against ~10 per point and surface in the search), which saves two of the ~12.7 evaluations per
+// point and keeps the call free of any state outside its arguments.
 // A wave therefore spends sum(iterations)/64 trips on a surface plus a short tail, 1.7 x fewer
 // evaluations than lanes bound to fixed points on the benchmark lattice.
 //
@@ -318,32 +128,7 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
 // at once, and each entry is then overwritten by the Black-Scholes price of the solved vol,
 // taken from Brent's last objective value (objective + target, exact at a root), so the static
 // and calendar checks cost no further normal CDFs.  Vols go straight to global memory.
-struct MatRow { double tau, sqrt_tau, disc, F, sdq; };
-struct __attribute__((aligned(32))) PointRow { double lnfk, fa, fb, ratio; };
-
-constexpr double BRENT_XA = 0.001, BRENT_XB = 3.0, BRENT_XTOL = 1e-6, BRENT_RTOL = 4 * 2.220446049250313e-16;
-constexpr int BRENT_MAXITER = 100;
-
-// Black-Scholes values at the bracket ends and log(F/K) for every grid point (one thread each).
-template <int VARIANT>
-__global__ __launch_bounds__(256) void point_table_kernel(GridView g, double spot)
-{
-    __shared__ double tab[ERFCX_LDS];
-    load_erfcx_table(tab);
-    __syncthreads();
-    const int per = g.nT * g.nK;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
-    const int t = i / g.nK, k = i - t * g.nK;
-    const BsPoint c = make_point(g, t, k, spot, VARIANT);
-    PointRow row;
-    row.lnfk = c.lnFK;
-    const afivm::ExpCoef ec = afivm::load_exp_coef();
-    row.fa = bs_objective<VARIANT>(c, BRENT_XA, tab, ec);
-    row.fb = bs_objective<VARIANT>(c, BRENT_XB, tab, ec);
-    row.ratio = c.ratio;
-    reinterpret_cast<PointRow *>(g.point)[i] = row;
-}
+struct MatRow { double tau, sqrt_tau, disc, F, sdq, fwd; };
 
 template <int GT>
 __device__ __forceinline__ void group_sync()
@@ -358,18 +143,11 @@ __device__ __forceinline__ void group_sync()
     }
 }
 
-// j / n for 0 <= j < 4096, 1 <= n <= 64 with inv = 1.0f / n (exact: (j + 1/2)/n is at least
-// 1/(2n) away from an integer, far more than the float rounding)
-__device__ __forceinline__ int small_div(int j, float inv) { return (int)(((float)j + 0.5f) * inv); }
-
-__device__ __forceinline__ bool opposite_sign(double a, double b)
-{
-    return ((__double2hiint(a) ^ __double2hiint(b)) < 0);
-}
-
 enum { PH_IDLE = 0, PH_ITER = 1, PH_DONE = 2 };
 
-template <int VARIANT, bool CHECKS, int GT, int THREADS>
+// FKTAB: the forward form's log(F/K) and F/K per lattice point are tabulated in LDS too (false: the
+// largest lattices, where that table does not fit, compute them as points are handed out).
+template <int VARIANT, bool CHECKS, int GT, int THREADS, bool FKTAB = true>
 __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const double *__restrict__ ratio,
                                                           int64_t N, double spot, double *__restrict__ iv_out,
                                                           int32_t *__restrict__ flags)
@@ -381,7 +159,10 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
     MatRow *mat = reinterpret_cast<MatRow *>(tab + ERFCX_LDS);                // [64]
     double *strike = reinterpret_cast<double *>(mat + AFIV_MAX_MATURITIES);   // [64]
     double *logm = strike + AFIV_MAX_STRIKES;            // [64]
-    double *price_all = logm + AFIV_MAX_STRIKES;         // [NG][per]
+    double *kmult = logm + AFIV_MAX_STRIKES;             // [64]
+    d2v *ends = reinterpret_cast<d2v *>(kmult + AFIV_MAX_STRIKES);            // [per] objective at the bracket ends
+    d2v *fk = ends + per;                                // [per] log(F/K), F/K (forward form only)
+    double *price_all = reinterpret_cast<double *>(fk + (VARIANT == AFIV_VARIANT_A && FKTAB ? per : 0));   // [NG][per]
     unsigned short *order = reinterpret_cast<unsigned short *>(price_all + (size_t)NG * per);   // [per] queue position -> lattice point
     __shared__ int skip_all[NG][AFIV_MAX_MATURITIES];
     __shared__ int ctr_all[NG][8];                       // queue head, nan, bad, static, calendar, butterfly
@@ -389,8 +170,6 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
     double *price = price_all + (size_t)gid * per;
     int *skip_t = skip_all[gid];
     int *ctr = ctr_all[gid];
-    const PointRow *__restrict__ point = reinterpret_cast<const PointRow *>(g.point);
-
     load_erfcx_table(tab);
     for (int t = tid; t < nT; t += THREADS) {
         MatRow m;
@@ -399,11 +178,13 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
         m.disc = g.disc_tau[t];
         m.F = spot * g.fwd_mult[t];
         m.sdq = spot * g.dq_tau[t];
+        m.fwd = g.fwd_mult[t];
         mat[t] = m;
     }
     for (int k = tid; k < nK; k += THREADS) {
         strike[k] = spot * g.Kmult[k];
         logm[k] = g.logm[k];
+        kmult[k] = g.Kmult[k];
     }
     for (int i = tid; i < per; i += THREADS) order[i] = g.order[i];
     __syncthreads();
@@ -412,6 +193,22 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
     const double nan = __builtin_nan("");
     const double rq = g.r - g.q;
     const afivm::ExpCoef ec = afivm::load_exp_coef();
+    // Black-Scholes values at the two bracket ends for every lattice point
+    for (int i = tid; i < per; i += THREADS) {
+        const int t = small_div(i, inv_nK), k = i - __mul24(t, nK);
+        const BsPoint c = make_point(g, t, k, spot, VARIANT);
+        d2v e;
+        e.x = bs_objective<VARIANT>(c, BRENT_XA, tab, ec);
+        e.y = bs_objective<VARIANT>(c, BRENT_XB, tab, ec);
+        ends[i] = e;
+        if (VARIANT == AFIV_VARIANT_A && FKTAB) {
+            d2v f;
+            f.x = c.lnFK;
+            f.y = c.ratio;
+            fk[i] = f;
+        }
+    }
+    __syncthreads();
     const double xa = BRENT_XA, xb = BRENT_XB, xtol = BRENT_XTOL, rtol = BRENT_RTOL;
 
     for (int64_t s = (int64_t)blockIdx.x * NG + gid; s < N; s += (int64_t)gridDim.x * NG) {
@@ -486,7 +283,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                     } else {
                         i_cur = order[j];
                         const int t = small_div(i_cur, inv_nK), k = i_cur - __mul24(t, nK);
-                        const PointRow pt = point[i_cur];
+                        const d2v pt = ends[i_cur];
                         const MatRow m = mat[t];
                         c.tau = m.tau;
                         c.sqrt_tau = m.sqrt_tau;
@@ -497,8 +294,18 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                         c.kdr = c.K * c.disc;
                         c.logm = logm[k];
                         c.rq = rq;
-                        c.lnFK = pt.lnfk;
-                        c.ratio = pt.ratio;
+                        // the per-point constants of make_point, from the staged rows
+                        if (VARIANT == AFIV_VARIANT_A && FKTAB) {
+                            const d2v pf = fk[i_cur];
+                            c.lnFK = pf.x;
+                            c.ratio = pf.y;
+                        } else if (VARIANT == AFIV_VARIANT_A) {
+                            c.ratio = c.F / c.K;
+                            c.lnFK = log(c.ratio);
+                        } else {
+                            c.lnFK = 0.0;
+                            c.ratio = kmult[k] * m.fwd;
+                        }
                         const double y = price[i_cur];
                         const double hp = y * spot * c.disc;
                         c.target = hp;
@@ -510,7 +317,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                             ok = !(hp < 1e-10 || isnan(y));
                         }
                         // brentq.c up to its loop, then the first half of the loop body for i = 0
-                        const double fa = pt.fa - hp, fb = pt.fb - hp;
+                        const double fa = pt.x - hp, fb = pt.y - hp;
                         res = nan;
                         fr = 0.0;
                         phase = PH_DONE;                 // rejected, or decided without iterating
@@ -743,30 +550,40 @@ int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t 
 }
 
 namespace {
-size_t surface_lds_bytes(const GridView &g, int groups)
+size_t surface_lds_bytes(const GridView &g, int groups, int variant, bool fktab = true)
 {
-    return sizeof(double) * ((size_t)ERFCX_LDS + 5 * AFIV_MAX_MATURITIES + 2 * AFIV_MAX_STRIKES +
-                             (size_t)groups * g.nT * g.nK) +
-           ((size_t)g.nT * g.nK * sizeof(unsigned short) + 7) / 8 * 8;
+    // erfcx table, maturity rows, three strike arrays, the per-point tables (bracket ends; the forward
+    // form also log(F/K) and F/K), the staged surfaces, the service order; the kernel's static arrays
+    // (skip flags and counters per group) come on top
+    const size_t per = (size_t)g.nT * g.nK;
+    const size_t tables = variant == AFIV_VARIANT_A && fktab ? 4 * per : 2 * per;
+    return sizeof(double) * ((size_t)ERFCX_LDS + 6 * AFIV_MAX_MATURITIES + 3 * AFIV_MAX_STRIKES + tables +
+                             (size_t)groups * per) +
+           (per * sizeof(unsigned short) + 7) / 8 * 8;
 }
 
-template <int VARIANT, bool CHECKS, int GT, int THREADS>
+size_t surface_static_lds(int groups) { return (size_t)groups * (AFIV_MAX_MATURITIES + 8) * sizeof(int); }
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+
+template <int VARIANT, bool CHECKS, int GT, int THREADS, bool FKTAB = true>
 int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
                           int32_t *flags, hipStream_t s)
 {
     constexpr int NG = THREADS / GT;
-    const size_t lds = surface_lds_bytes(g, NG);
+    const size_t lds = surface_lds_bytes(g, NG, VARIANT, FKTAB);
+    if (lds + surface_static_lds(NG) > LDS_PER_CU) return AFIV_E_SHAPE;
     if (lds > 48 * 1024) {
         // raising the dynamic-LDS limit is a per-function attribute, not an allocation
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
     }
-    const int per = g.nT * g.nK;
-    hipLaunchKernelGGL(point_table_kernel<VARIANT>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, g, spot);
+    // few, long-lived workgroups: each one tabulates the bracket ends of the whole lattice first
     int64_t blocks = (N + NG - 1) / NG;
-    if (blocks > 256 * 24) blocks = 256 * 24;
-    hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS, GT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), lds,
+    const int64_t cap = GT == 64 ? 256 * 4 : 256 * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>), dim3((unsigned)blocks), dim3(THREADS), lds,
                        s, g, ratio, N, spot, iv_out, flags);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -775,9 +592,19 @@ template <int VARIANT, bool CHECKS>
 int launch_surface_grouped(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
                            int32_t *flags, hipStream_t s)
 {
-    // a wave per surface needs surfaces enough to fill the chip and room for two workgroups per CU
-    if (N >= 2048 && surface_lds_bytes(g, AFIV_IV_THREADS / 64) <= 76 * 1024)
-        return launch_surface_kernel<VARIANT, CHECKS, 64, AFIV_IV_THREADS>(g, ratio, N, spot, iv_out, flags, s);
+    // A wave per surface needs surfaces enough to fill the chip.  Sixteen waves per CU where the
+    // lattice's LDS footprint allows it: two workgroups of eight surfaces, else one of sixteen, else
+    // two of four; a workgroup per surface otherwise.
+    if (N >= 2048) {
+        if (2 * (surface_lds_bytes(g, 8, VARIANT) + surface_static_lds(8)) <= LDS_PER_CU)
+            return launch_surface_kernel<VARIANT, CHECKS, 64, 512>(g, ratio, N, spot, iv_out, flags, s);
+        if (surface_lds_bytes(g, 16, VARIANT) + surface_static_lds(16) <= LDS_PER_CU)
+            return launch_surface_kernel<VARIANT, CHECKS, 64, 1024>(g, ratio, N, spot, iv_out, flags, s);
+        if (2 * (surface_lds_bytes(g, 4, VARIANT) + surface_static_lds(4)) <= LDS_PER_CU)
+            return launch_surface_kernel<VARIANT, CHECKS, 64, 256>(g, ratio, N, spot, iv_out, flags, s);
+    }
+    if (VARIANT == AFIV_VARIANT_A && surface_lds_bytes(g, 1, VARIANT) + surface_static_lds(1) > LDS_PER_CU)
+        return launch_surface_kernel<VARIANT, CHECKS, 256, 256, false>(g, ratio, N, spot, iv_out, flags, s);
     return launch_surface_kernel<VARIANT, CHECKS, 256, 256>(g, ratio, N, spot, iv_out, flags, s);
 }
 }  // namespace
@@ -787,7 +614,8 @@ int afiv_launch_surface_iv(const GridView &g, const double *ratio, int64_t N, do
                            double *iv_out, int32_t *flags, hipStream_t s)
 {
     if (N <= 0) return 0;
-    if (variant == 0)
+    if (variant == AFIV_VARIANT_A) return afiv_launch_fast_iv(g, ratio, N, spot, iv_out, flags, s);
+    if (variant == AFIV_VARIANT_A_BRENT)
         return flags ? launch_surface_grouped<0, true>(g, ratio, N, spot, iv_out, flags, s)
                      : launch_surface_grouped<0, false>(g, ratio, N, spot, iv_out, flags, s);
     return flags ? launch_surface_grouped<1, true>(g, ratio, N, spot, iv_out, flags, s)

@@ -1,0 +1,332 @@
+// Implied volatility for the forward Black-Scholes form (variant A) and the arbitrage checks on
+// the re-priced vols, one wave per surface, lanes marching through the lattice in natural order.
+//
+// Compiled with -ffp-contract=off (see afiv_bs.h).
+//
+// What is kept from the reference (generate_iv_surface_by_date.py:296-318): the guard, the bracket
+// [0.001, 3.0] and scipy.optimize.brentq's rules for it -- f(0.001) == 0 returns 0.001, equal signs
+// at the two ends give NaN -- evaluated with the very objective the Brent kernel (afiv_ivarb.hip)
+// uses, so the NaN mask is that kernel's bit for bit.  What differs is how the root inside a valid
+// bracket is found.  Variant A's objective is increasing in the vol, so any method that converges
+// lands within the reference's xtol = 1e-6 of brentq's answer; this kernel takes
+//   1. a closed-form first guess: the NORMAL-model (Bachelier) implied vol of the option's
+//      out-of-the-money value -- a one-variable inverse, two small float32 tables
+//      (tools/gen_bachelier_table.py) -- converted to a lognormal vol by the first term of the
+//      normal/lognormal expansion, s_LN = s_N (theta/m) / (1 - s_N^2/24): relative error 1e-6 at the
+//      median and below 1e-4 for total vols under 1;
+//   2. third-order Householder steps on the objective itself (its derivatives are closed forms of
+//      d1, d2 and the exponential the evaluation has computed anyway), each candidate kept inside
+//      the bracket (bisection otherwise), until the Newton step is below 1e-8 or the objective is
+//      zero to the rounding of its own terms.
+// Two evaluations per point on the benchmark lattice (one where the guess is already within 1e-8)
+// instead of Brent's ten, the same for every lane: a wave solves 64 consecutive lattice points in
+// lockstep, reads and writes them coalesced, and compares neighbours (strike k-1, maturity t-1)
+// through cross-lane moves instead of staging the surface in LDS.
+//
+// Where the objective is flat to rounding (deep in the money, a time value below one ulp of the
+// price) every vol of a whole interval is a root in double precision; brentq's pick depends on its
+// path, this kernel returns the one its guess lands on.  Both re-price to the target to within the
+// rounding of the objective.
+#include "afiv_bs.h"
+#include "bachelier_table.inc"
+
+namespace {
+using namespace afivbs;
+
+constexpr int FAST_THREADS = 256;
+constexpr int FAST_WAVES = FAST_THREADS / 64;
+constexpr int BACH_ROW = 8;                       // 5 coefficients padded to 32-byte rows
+constexpr int BACH_ROWS = AFIV_BACH_NSEG_A + AFIV_BACH_NSEG_B;
+static_assert(AFIV_BACH_NCOEF == 5, "bachelier table degree");
+__constant__ float c_bach_a[AFIV_BACH_NSEG_A * AFIV_BACH_NCOEF] = {AFIV_BACH_TABLE_A};
+__constant__ float c_bach_b[AFIV_BACH_NSEG_B * AFIV_BACH_NCOEF] = {AFIV_BACH_TABLE_B};
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+struct FastMat {
+    double tau, sqrt_tau, disc, F;
+    double kv;          // vega = kv * exp(-d1^2/2)/2:  disc F sqrt(tau) 2/sqrt(2 pi)
+    double ffloor;      // rounding level of the objective's terms: 8 eps disc F
+    float rsqrt_tau, inv_disc;
+};
+
+__device__ __forceinline__ float bach_poly(const float *__restrict__ rows, float t, int nseg)
+{
+    // fmaxf / fminf return the other operand for a NaN: the index is always inside the table
+    const float tc = fminf(fmaxf(t, 0.0f), (float)nseg - 0.001f);
+    const int seg = (int)tc;
+    const float f = tc - (float)seg - 0.5f;
+    const float *r = rows + seg * BACH_ROW;
+    const f4v c = *reinterpret_cast<const f4v *>(r);
+    float p = r[4];
+    p = fmaf(p, f, c.w);
+    p = fmaf(p, f, c.z);
+    p = fmaf(p, f, c.y);
+    return fmaf(p, f, c.x);
+}
+
+// First guess for the root of BS(sigma) = target: see the file comment.  otm = the target's
+// out-of-the-money (time) value, discounted.  Everything in float: a guess needs 1e-5.
+__device__ __forceinline__ double first_guess(double otm, double F, double K, double lnfk, const FastMat &m,
+                                              const float *__restrict__ bach)
+{
+    const float th = fabsf((float)lnfk);
+    const float th2 = th * th;
+    const float ser = fmaf(th2, fmaf(th2, 1.0f / 1920.0f, 1.0f / 24.0f), 1.0f);   // sinh(th/2)/(th/2)
+    const float mny = th * ser;                                                  // |F - K| / sqrt(F K)
+    const float inv_norm = __builtin_amdgcn_rsqf((float)F * (float)K) * m.inv_disc;
+    const double beta_d = otm * (double)inv_norm;            // option value in units of sqrt(F K)
+    const float beta = (float)beta_d;
+    const float w = fmaf(0.5f, mny, beta);
+    const float u = mny * __builtin_amdgcn_rcpf(w);
+    const float s_a = w * bach_poly(bach, u * ((float)AFIV_BACH_NSEG_A / AFIV_BACH_UA), AFIV_BACH_NSEG_A);
+    // log(beta / mny) from the double's exponent and mantissa: beta may be far below float's range
+    const double rho = beta_d * (double)__builtin_amdgcn_rcpf(mny);
+    const float lg2 = (float)__builtin_amdgcn_frexp_exp(rho) + __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(rho));
+    const float zeta = __builtin_amdgcn_sqrtf(fmaxf(-2.0f * 0.693147181f * lg2, 0.0f));
+    const float s_b = mny * bach_poly(bach + AFIV_BACH_NSEG_A * BACH_ROW,
+                                      (zeta - AFIV_BACH_ZL) * ((float)AFIV_BACH_NSEG_B / (AFIV_BACH_ZH - AFIV_BACH_ZL)),
+                                      AFIV_BACH_NSEG_B);
+    const float s_n = u <= 1.7f ? s_a : s_b;                 // normal total vol, units of sqrt(F K)
+    const float s_ln = s_n * __builtin_amdgcn_rcpf(ser * fmaf(s_n * s_n, -1.0f / 24.0f, 1.0f));
+    return (double)(s_ln * m.rsqrt_tau);
+}
+
+// v_rcp_f64 and one Newton step: 1e-10 relative, ample for a root finder's step
+__device__ __forceinline__ double rcp_step(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+
+template <bool CHECKS>
+__global__ __launch_bounds__(FAST_THREADS) void iv_fast_kernel(GridView g, const double *__restrict__ ratio,
+                                                               int64_t N, double spot, double *__restrict__ iv_out,
+                                                               int32_t *__restrict__ flags)
+{
+    extern __shared__ double dyn[];
+    const int nT = g.nT, nK = g.nK, per = nT * nK;
+    double *tab = dyn;                                                         // ERFCX_LDS
+    FastMat *mat = reinterpret_cast<FastMat *>(tab + ERFCX_LDS);               // [64]
+    double *strike = reinterpret_cast<double *>(mat + AFIV_MAX_MATURITIES);    // [64]
+    d2v *ends = reinterpret_cast<d2v *>(strike + AFIV_MAX_STRIKES);            // [per] objective at 0.001 and 3.0
+    d2v *fk = ends + per;                                                      // [per] log(F/K), F/K
+    float *bach = reinterpret_cast<float *>(fk + per);                         // [BACH_ROWS][BACH_ROW]
+    __shared__ int skip_all[FAST_WAVES][AFIV_MAX_MATURITIES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *skip_t = skip_all[wave];
+
+    load_erfcx_table(tab);
+    for (int i = tid; i < BACH_ROWS * BACH_ROW; i += FAST_THREADS) {
+        const int row = i / BACH_ROW, j = i - row * BACH_ROW;
+        float v = 0.0f;
+        if (j < AFIV_BACH_NCOEF)
+            v = row < AFIV_BACH_NSEG_A ? c_bach_a[row * AFIV_BACH_NCOEF + j]
+                                       : c_bach_b[(row - AFIV_BACH_NSEG_A) * AFIV_BACH_NCOEF + j];
+        bach[i] = v;
+    }
+    for (int t = tid; t < nT; t += FAST_THREADS) {
+        FastMat m;
+        m.tau = g.tau[t];
+        m.sqrt_tau = sqrt(m.tau);
+        m.disc = g.disc_tau[t];
+        m.F = spot * g.fwd_mult[t];
+        m.kv = m.disc * m.F * m.sqrt_tau * 0.7978845608028654;
+        m.ffloor = 8.0 * 2.220446049250313e-16 * m.disc * m.F;
+        m.rsqrt_tau = (float)(1.0 / m.sqrt_tau);
+        m.inv_disc = (float)(1.0 / m.disc);
+        mat[t] = m;
+    }
+    for (int k = tid; k < nK; k += FAST_THREADS) strike[k] = spot * g.Kmult[k];
+    __syncthreads();
+
+    const float inv_nK = 1.0f / (float)nK;
+    const double nan = __builtin_nan("");
+    const afivm::ExpCoef ec = afivm::load_exp_coef();
+    const double xa = BRENT_XA, xb = BRENT_XB;
+    // the objective at the two bracket ends, and the per-point constants, for every lattice point
+    for (int i = tid; i < per; i += FAST_THREADS) {
+        const int t = small_div(i, inv_nK), k = i - __mul24(t, nK);
+        const BsPoint c = make_point(g, t, k, spot, AFIV_VARIANT_A);
+        d2v e, f;
+        e.x = bs_objective<AFIV_VARIANT_A>(c, xa, tab, ec);
+        e.y = bs_objective<AFIV_VARIANT_A>(c, xb, tab, ec);
+        f.x = c.lnFK;
+        f.y = c.ratio;
+        ends[i] = e;
+        fk[i] = f;
+    }
+    __syncthreads();
+
+    const int nbatch = (per + 63) >> 6;
+    for (int64_t s = (int64_t)blockIdx.x * FAST_WAVES + wave; s < N; s += (int64_t)gridDim.x * FAST_WAVES) {
+        const double *src = ratio + s * per;
+        double *dst = iv_out + s * per;
+        if (CHECKS) {
+            // maturities whose ratios hold a NaN or a negative value take no part in the butterfly rule
+            __builtin_amdgcn_wave_barrier();
+            skip_t[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < per; i += 64) {
+                const double y = src[i];
+                if (isnan(y) || y < 0) skip_t[small_div(i, inv_nK)] = 1;       // benign race: all writers store 1
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        int n_nan = 0, n_bad = 0, n_fly = 0, n_stat = 0, n_cal = 0;
+        double p_prev = nan;                                 // re-priced values of the previous 64 points
+        for (int b = 0; b < nbatch; ++b) {
+            const int i = (b << 6) + lane;
+            const bool live = i < per;
+            const int ic = live ? i : per - 1;
+            const int t = small_div(ic, inv_nK), k = ic - __mul24(t, nK);
+            const FastMat m = mat[t];
+            const d2v pe = ends[ic], pf = fk[ic];
+            BsPoint c;
+            c.tau = m.tau;
+            c.sqrt_tau = m.sqrt_tau;
+            c.disc = m.disc;
+            c.F = m.F;
+            c.K = strike[k];
+            c.lnFK = pf.x;
+            c.ratio = pf.y;
+            const double y = src[ic];
+            const double hp = y * spot * c.disc;
+            c.target = hp;
+            const double intrinsic = fmax(c.F - c.K, 0.0) * c.disc;
+            const bool ok = !(hp < intrinsic * 0.99);
+            // brentq up to its loop
+            const double fa = pe.x - hp, fb = pe.y - hp;
+            double res = nan, pr = hp;
+            bool go = false;
+            if (ok && !isnan(fa) && !isnan(fb)) {
+                if (fa == 0) res = xa;
+                else if (fb == 0) res = xb;
+                else if (opposite_sign(fa, fb)) go = live;
+            }
+            double sig = first_guess(hp - intrinsic, c.F, c.K, c.lnFK, m, bach);
+            if (!(sig > xa && sig < xb)) sig = 0.5 * (xa + xb);
+            double lo = xa, hi = xb;
+            const bool lo_neg = fa < 0;                       // sign of the objective at the low end
+            int it = 0;
+            while (__ballot(go)) {
+                BsAux ax;
+                const double bsv = bs_objective<AFIV_VARIANT_A>(c, sig, tab, ec, &ax);
+                const double f = bsv - hp;
+                if (go) {
+                    ++it;
+                    const double v = m.kv * ax.e;
+                    const double af = fabs(f);
+                    // on the low side of the root?  (f == 0 is accepted below)
+                    const bool low = (f < 0) == lo_neg;
+                    lo = low ? sig : lo;
+                    hi = low ? hi : sig;
+                    const bool fail = isnan(f) || it >= BRENT_MAXITER;
+                    if (fail || af <= 1e-8 * v || af <= m.ffloor || hi - lo < 1e-6) {
+                        res = fail ? nan : sig;
+                        pr = fail ? hp : bsv;
+                        go = false;
+                    } else {
+                        // Householder's third-order step: nu (1 + g nu / 2) / (1 + g nu + d nu^2 / 6) with
+                        // nu = -f/f', g = f''/f' = d1 d2 / sigma, d = f'''/f' = g^2 - (d1^2 + d1 d2 + d2^2)/sigma^2
+                        const double nu = -f * rcp_step(v);
+                        const double rs = rcp_step(sig);
+                        const double dd = ax.d1 * ax.d2;
+                        const double gm = dd * rs;
+                        const double dl = gm * gm - (ax.d1 * ax.d1 + dd + ax.d2 * ax.d2) * (rs * rs);
+                        const double gn = gm * nu;
+                        const double num = nu * (1.0 + 0.5 * gn);
+                        const double den = 1.0 + gn + dl * (nu * nu) * (1.0 / 6.0);
+                        const double cand = sig + num * rcp_step(den);
+                        sig = (cand > lo && cand < hi) ? cand : 0.5 * (lo + hi);
+                    }
+                }
+            }
+            if (live) dst[i] = res;
+            if (CHECKS) {
+                if (live) {
+                    if (isnan(res)) { n_nan++; n_bad++; }
+                    else if (res <= 0) n_bad++;
+                }
+                // static: strikes k-1, k of one maturity; calendar: maturities t-1, t of one strike.
+                // The neighbours sit 1 and nK lattice points back: in this batch or the previous one.
+                const double p_cur = live ? pr : nan;
+                const double up1 = __shfl(p_cur, (lane + 63) & 63, 64);
+                const double last = __shfl(p_prev, 63, 64);   // (cross-lane reads stay outside the selects:
+                const double left = lane == 0 ? last : up1;   //  a read under a lane mask returns 0 for the others)
+                const int back = (lane - nK) & 63;
+                const double c_cur = __shfl(p_cur, back, 64), c_prev = __shfl(p_prev, back, 64);
+                const double below = lane >= nK ? c_cur : c_prev;
+                if (live && k >= 1 && left < p_cur - 1e-6) n_stat++;
+                if (live && t >= 1 && below > p_cur + 1e-6) n_cal++;
+                if (live && k + 2 < nK && !skip_t[t]) {
+                    const double bf = y - 2 * src[i + 1] + src[i + 2];
+                    if (bf < 0) n_fly++;
+                }
+                p_prev = p_cur;
+            }
+        }
+        if (CHECKS) {
+            n_nan = wave_sum(n_nan);
+            n_bad = wave_sum(n_bad);
+            n_fly = wave_sum(n_fly);
+            n_stat = wave_sum(n_stat);
+            n_cal = wave_sum(n_cal);
+            if (lane == 0) {
+                const bool valid = n_bad == 0;
+                const int st = valid ? n_stat : -1;
+                const int ca = valid ? n_cal : -1;
+                int status = 0;
+                if (valid && st == 0 && ca == 0) status |= 1;
+                if (n_fly == 0) status |= 2;
+                if (valid) status |= 4;
+                if ((double)n_nan / (double)per < 0.1) status |= 8;
+                if (n_nan == 0) status |= 16;
+                flags[4 * s + 0] = st;
+                flags[4 * s + 1] = ca;
+                flags[4 * s + 2] = n_fly;
+                flags[4 * s + 3] = status;
+            }
+        }
+    }
+}
+
+size_t fast_lds_bytes(const GridView &g)
+{
+    const size_t per = (size_t)g.nT * g.nK;
+    return sizeof(double) * ((size_t)ERFCX_LDS + AFIV_MAX_STRIKES + 4 * per) + sizeof(FastMat) * AFIV_MAX_MATURITIES +
+           sizeof(float) * BACH_ROWS * BACH_ROW;
+}
+
+template <bool CHECKS>
+int launch_fast(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out, int32_t *flags,
+                hipStream_t s)
+{
+    const size_t lds = fast_lds_bytes(g);
+    if (lds > 48 * 1024) {
+        // raising the dynamic-LDS limit is a per-function attribute, not an allocation
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&iv_fast_kernel<CHECKS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+    }
+    // long-lived workgroups (each tabulates the bracket ends of the lattice first), a wave per surface
+    int64_t blocks = (N + FAST_WAVES - 1) / FAST_WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((iv_fast_kernel<CHECKS>), dim3((unsigned)blocks), dim3(FAST_THREADS), lds, s, g, ratio, N, spot,
+                       iv_out, flags);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+// variant A: implied vols and (flags != nullptr) the checks in one pass
+int afiv_launch_fast_iv(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
+                        int32_t *flags, hipStream_t s)
+{
+    if (N <= 0) return 0;
+    return flags ? launch_fast<true>(g, ratio, N, spot, iv_out, flags, s)
+                 : launch_fast<false>(g, ratio, N, spot, iv_out, flags, s);
+}

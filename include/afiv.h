@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AFIV_VERSION 100
+#define AFIV_VERSION 200
 
 enum {
     AFIV_OK = 0,
@@ -40,10 +40,18 @@ enum {
     AFIV_E_WORKSPACE = -5    /* the call needs a workspace the grid was created without */
 };
 
-/* Which Black-Scholes form is inverted / re-priced. */
+/* Which Black-Scholes form is inverted / re-priced, and for the forward form how its root is
+ * found.  The forward form's objective increases with the vol, so every convergent method lands
+ * within the reference's xtol = 1e-6 of scipy.optimize.brentq's answer: AFIV_VARIANT_A uses a
+ * closed-form first guess and Householder steps (two objective evaluations per point),
+ * AFIV_VARIANT_A_BRENT walks brentq's own iteration path (about ten).  Both apply brentq's rules at
+ * the bracket ends with the same arithmetic, so their NaN masks are identical.  The spot form's
+ * objective is not monotone (the reference's sign convention), so it is always solved on brentq's
+ * path.  Only AFIV_VARIANT_A and AFIV_VARIANT_B are valid as a `bs_form`. */
 enum {
-    AFIV_VARIANT_A = 0,  /* forward form, generate_iv_surface_by_date.py:308-312 */
-    AFIV_VARIANT_B = 1   /* spot form as written in generate_regime_surfaces.py:154-159 */
+    AFIV_VARIANT_A = 0,        /* forward form, generate_iv_surface_by_date.py:308-312 */
+    AFIV_VARIANT_B = 1,        /* spot form as written in generate_regime_surfaces.py:154-159 */
+    AFIV_VARIANT_A_BRENT = 2   /* forward form, brentq's iteration path step for step */
 };
 
 /* Limits of this build. */

@@ -62,7 +62,7 @@ def price_ratio(p, r, q, logm, tau, X, W):
     return c / mp.exp(-r * mp.mpf(float(tau)))
 
 
-def main():
+def small_vol_of_vol():
     X, W = laguerre_tables()
     rng = np.random.default_rng(77)
     sets = []
@@ -86,5 +86,36 @@ def main():
     np.savez(os.path.join(HERE, "exact_prices.npz"), params=params, tau=tau, logm=logm, r=r, q=q, ratio=out)
 
 
+def corners():
+    """exact_prices_corners.npz: (a) the corner rows of the calibration box where the
+    double-precision oracle is noisiest (large kappa theta T / sigma_v^2), with the day-count
+    truncation on and off; (b) the series branch the reference takes at sigma_v <= 1e-5, evaluated
+    as written, sigma_v = 0 included (0/0: NaN)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import exact
+    r, q = 0.067, 0.0
+    tau = np.array([0.02, 0.9, 5.0])            # 7.3, 328.5 and 1825 days
+    logm = np.array([-0.2, -0.1, 0.0, 0.1, 0.2])
+    main_rows = [[kappa, theta, sigma, rho, v0]
+                 for kappa in (2.0, 20.0) for theta in (0.25, 2.0) for sigma in (1e-4, 1e-3)
+                 for rho in (-0.999, -0.5, 0.5, 0.999) for v0 in (0.01, 0.25)]
+    series_rows = [[kappa, theta, sigma, rho, v0]
+                   for sigma in (1e-5, 5e-6, 0.0) for kappa, theta in ((2.0, 0.04), (0.5, 0.09), (20.0, 2.0))
+                   for rho, v0 in ((-0.5, 0.04), (0.3, 0.02), (-0.999, 0.25), (0.999, 0.01))]
+    params = np.array(main_rows + series_rows)
+    out = np.zeros((2, len(params), len(tau), len(logm)))
+    for i, p in enumerate(params):
+        for ti, trunc in enumerate((True, False)):
+            out[ti, i] = exact.price_ratio_grid(p[None], logm, tau, r, q, trunc)[0]
+        print(i, p.tolist(), out[0, i, 1, 2], out[1, i, 2, 4], flush=True)
+    np.savez(os.path.join(HERE, "exact_prices_corners.npz"), params=params, tau=tau, logm=logm, r=r, q=q,
+             ratio_trunc=out[0], ratio_exact_tau=out[1], n_main=len(main_rows))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "corners" in sys.argv[1:]:
+        corners()
+    else:
+        small_vol_of_vol()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(afiv):
     for s in declared_symbols():
         assert hasattr(lib, s), f"libafiv.so does not export {s}"
     assert set(afiv._lib.SIGNATURES) == set(declared_symbols())
-    assert lib.afiv_version() == 100
+    assert lib.afiv_version() == 200
 
 
 def test_error_strings_and_null_checks_without_gpu(afiv):

@@ -82,7 +82,7 @@ def test_config1_repo_default_100_samples(afiv, golden_dir):
     ref_ratio = oracle.price_ratio_grid(p, LOGM_GRID, T_GRID, R, Q)
     assert np.all(np.abs(ratio.cpu().numpy() - ref_ratio) <= price_tol(ref_ratio, p))
     iv_o = oracle.implied_vol_grid(ratio.cpu().numpy(), LOGM_GRID, T_GRID, SPOT, R, Q, "A")
-    assert_iv_close(iv.cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q)
+    assert_iv_close(iv.cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q, same_path=False)
     flags_o = oracle.arb_check(iv.cpu().numpy(), ratio.cpu().numpy(), LOGM_GRID, T_GRID, SPOT, R, Q, "A")
     assert np.array_equal(flags.cpu().numpy(), flags_o)
     # the reference's success rule (generate_iv_surface_by_date.py:321) from the status word
@@ -116,7 +116,7 @@ def test_config2_all_dates_100_samples_each(afiv, golden_dir):
     got = ratio[pick].cpu().numpy()
     assert np.all(np.abs(got - ref_ratio) <= price_tol(ref_ratio, p))
     iv_o = oracle.implied_vol_grid(got, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
-    assert_iv_close(iv[pick].cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q)
+    assert_iv_close(iv[pick].cpu().numpy(), iv_o, LOGM_GRID, T_GRID, SPOT, R, Q, same_path=False)
     flags_o = oracle.arb_check(iv[pick].cpu().numpy(), got, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
     assert np.array_equal(flags[pick].cpu().numpy(), flags_o)
 
@@ -159,7 +159,7 @@ def test_config3_benchmark_lattice_at_batch_size(afiv):
     ref_ratio = oracle.price_ratio_grid(p, logm, tau, R, Q)
     assert np.all(np.abs(got - ref_ratio) <= price_tol(ref_ratio, p))
     iv_o = oracle.implied_vol_grid(got, logm, tau, SPOT, R, Q, "A")
-    assert_iv_close(iv[pick].cpu().numpy(), iv_o, logm, tau, SPOT, R, Q)
+    assert_iv_close(iv[pick].cpu().numpy(), iv_o, logm, tau, SPOT, R, Q, same_path=False)
     flags_o = oracle.arb_check(iv[pick].cpu().numpy(), got, logm, tau, SPOT, R, Q, "A")
     assert np.array_equal(flags[pick].cpu().numpy(), flags_o)
 
@@ -245,7 +245,7 @@ def test_config5_stress_grid(afiv):
         iv_o = oracle.implied_vol_grid(ratio, LOGM_GRID, tau, SPOT, R, Q, variant)
         print(f"variant {variant}: NaN on GPU {int(np.isnan(iv).sum())}, oracle {int(np.isnan(iv_o).sum())}, "
               f"mask mismatches {int((np.isnan(iv) != np.isnan(iv_o)).sum())}")
-        assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, max_ill_mismatch=0.01)
+        assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, max_ill_mismatch=0.01, same_path=variant != "A")
     flags = grid.arb_check(dev(iv_o), dev(ratio), SPOT, "B").cpu().numpy()
     assert np.array_equal(flags, oracle.arb_check(iv_o, ratio, LOGM_GRID, tau, SPOT, R, Q, "B"))
 

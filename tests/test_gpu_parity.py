@@ -12,7 +12,12 @@ Tolerances (from the north-star statement, made well-posed):
   IV      |d| <= 1e-6 absolute and identical NaN masks wherever the inversion is well
           conditioned (Black-Scholes vega >= 1e-3 in spot units, i.e. a one-ulp change of a
           21000-scale price moves the root by < 1e-8).  Below that, SciPy's own Cephes erfc and
-          the C library's differ by an ulp and Brent's path -- even the bracket test -- flips.
+          the C library's differ by an ulp and Brent's path -- even the bracket test -- flips:
+          there a vol must either agree to 1e-6 or RE-PRICE to the reference vol's value within
+          the rounding of the objective's own terms (64 eps F exp(-r tau)): where the time value
+          is below an ulp of the price a whole interval of vols solves the equation in double
+          precision, and which of them a root finder returns depends on its path.  The kernels
+          that walk brentq's path (variants "A_BRENT", "B") are additionally held to 1e-4 there.
   flags   bit-exact given identical IV / ratio inputs
   decode  float32, |d| <= 2e-5 * max(1, |x|) (summation order differs from torch's GEMM)
 """
@@ -56,8 +61,28 @@ def vega(iv, logm, tau, spot, r, q):
         return np.exp(-r * T) * F * norm.pdf(d1) * np.sqrt(T)
 
 
-def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002):
-    """IV parity rule of the module docstring."""
+def reprice_a(iv, logm, tau, spot, r, q):
+    """Forward-form Black-Scholes value of every vol (generate_iv_surface_by_date.py:309-311)."""
+    from scipy.special import ndtr
+    T = np.asarray(tau)[None, :, None]
+    lm = np.asarray(logm)[None, None, :]
+    F = spot * np.exp((r - q) * T)
+    K = spot * np.exp(lm)
+    with np.errstate(all="ignore"):
+        d1 = (np.log(F / K) + 0.5 * iv ** 2 * T) / (iv * np.sqrt(T))
+        d2 = d1 - iv * np.sqrt(T)
+        return (np.exp(-r * T) * (F * ndtr(d1) - K * ndtr(d2)),
+                np.broadcast_to(64 * EPS * F * np.exp(-r * T), np.shape(iv)))
+
+
+def oracle_variant(variant):
+    """The oracle knows the two Black-Scholes forms; "A_BRENT" is the forward form on brentq's path."""
+    return "A" if variant == "A_BRENT" else variant
+
+
+def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002, same_path=True):
+    """IV parity rule of the module docstring.  ``same_path``: the kernel walks brentq's own
+    iterations, so even ill-conditioned roots are expected within 1e-4."""
     v_ref = vega(ref, logm, tau, spot, r, q)
     v_got = vega(got, logm, tau, spot, r, q)
     v = np.where(np.isnan(v_ref), v_got, v_ref)
@@ -71,8 +96,14 @@ def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002):
     d = np.abs(got[m] - ref[m])
     assert d.size == 0 or d.max() <= 1e-6, f"max IV difference {d.max():.3g}"
     m2 = ~well & ~both_nan & ~mism
-    d2 = np.abs(got[m2] - ref[m2])
-    assert d2.size == 0 or d2.max() <= 1e-4, f"ill-conditioned IV difference {d2.max():.3g}"
+    d2 = np.abs(got - ref)
+    if same_path:
+        assert not m2.any() or d2[m2].max() <= 1e-4, f"ill-conditioned IV difference {d2[m2].max():.3g}"
+    else:
+        p_got, unit = reprice_a(got, logm, tau, spot, r, q)
+        p_ref, _ = reprice_a(ref, logm, tau, spot, r, q)
+        bad = m2 & (d2 > 1e-6) & ~(np.abs(p_got - p_ref) <= unit)
+        assert not bad.any(), f"{bad.sum()} ill-conditioned vols neither agree nor re-price alike, worst {d2[bad].max():.3g}"
 
 
 def assert_params_close(got, ref):
@@ -104,7 +135,7 @@ def grid821(afiv):
 
 
 def test_library_reports_version(afiv):
-    assert afiv._lib.lib().afiv_version() == 100
+    assert afiv._lib.lib().afiv_version() == 200
 
 
 def test_price_matches_golden_and_oracle(afiv, grid821, golden_dir):
@@ -176,25 +207,25 @@ def test_small_vol_of_vol_series_branch(afiv, grid821):
     assert np.all(np.abs(got - ref)[fin] <= 1e-7)
 
 
-@pytest.mark.parametrize("variant", ["A", "B"])
+@pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
 def test_implied_vol_matches_scipy_golden(afiv, grid821, golden_dir, variant):
     g = np.load(f"{golden_dir}/golden_iv.npz")
-    ref = g["iv_a"] if variant == "A" else g["iv_b"]
+    ref = g["iv_b"] if variant == "B" else g["iv_a"]
     got = grid821.implied_vol(dev(g["ratio"]), float(g["spot"]), variant).cpu().numpy()
     if variant == "B":          # no ill-conditioned points in this set: everything must agree
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         m = ~np.isnan(ref)
         assert np.all(np.abs(got[m] - ref[m]) <= 1e-6)
-    assert_iv_close(got, ref, LOGM_GRID, T_GRID, float(g["spot"]), R, Q)
+    assert_iv_close(got, ref, LOGM_GRID, T_GRID, float(g["spot"]), R, Q, same_path=variant != "A")
 
 
-@pytest.mark.parametrize("variant", ["A", "B"])
+@pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
 def test_implied_vol_matches_c_oracle(afiv, grid821, variant):
     p = sample_params(64, 5)
     ratio = oracle.price_ratio_grid(p, LOGM_GRID, T_GRID, R, Q)
-    ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, SPOT, R, Q, variant)
+    ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, SPOT, R, Q, oracle_variant(variant))
     got = grid821.implied_vol(dev(ratio), SPOT, variant).cpu().numpy()
-    assert_iv_close(got, ref, LOGM_GRID, T_GRID, SPOT, R, Q)
+    assert_iv_close(got, ref, LOGM_GRID, T_GRID, SPOT, R, Q, same_path=variant != "A")
 
 
 def test_implied_vol_edge_inputs(afiv, grid821):
@@ -202,8 +233,8 @@ def test_implied_vol_edge_inputs(afiv, grid821):
     ratio[1] = np.nan
     ratio[2] = -1e-12
     ratio[3] = 5.0            # above any attainable call value
-    for variant in ("A", "B"):
-        ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, SPOT, R, Q, variant)
+    for variant in ("A", "A_BRENT", "B"):
+        ref = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, SPOT, R, Q, oracle_variant(variant))
         got = grid821.implied_vol(dev(ratio), SPOT, variant).cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         m = ~np.isnan(ref)
@@ -242,7 +273,7 @@ def test_surface_end_to_end_matches_oracle(afiv, grid821):
     assert np.all(np.abs(ratio - ratio_r) <= price_tol(ratio_r, p))
     # Stage-wise: IV and flags on the GPU's own ratios must equal the oracle run on those ratios.
     iv_o = oracle.implied_vol_grid(ratio, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
-    assert_iv_close(iv, iv_o, LOGM_GRID, T_GRID, SPOT, R, Q)
+    assert_iv_close(iv, iv_o, LOGM_GRID, T_GRID, SPOT, R, Q, same_path=False)
     flags_o = oracle.arb_check(iv, ratio, LOGM_GRID, T_GRID, SPOT, R, Q, "A")
     assert np.array_equal(flags, flags_o)
     # End to end only the NaN mask / success bit are compared where prices sit on a guard edge.
@@ -251,7 +282,7 @@ def test_surface_end_to_end_matches_oracle(afiv, grid821):
     assert np.mean((flags[:, 3] & 8) == (flags_r[:, 3] & 8)) > 0.97
 
 
-@pytest.mark.parametrize("variant", ["A", "B"])
+@pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
 def test_fused_iv_and_checks_equal_the_two_separate_passes(afiv, grid821, variant):
     p = sample_params(300, 17)
     ratio = grid821.price(dev(p))
@@ -260,7 +291,7 @@ def test_fused_iv_and_checks_equal_the_two_separate_passes(afiv, grid821, varian
     noisy[::4] += torch.as_tensor(1e-4 * rng.standard_normal(tuple(noisy[::4].shape)), device="cuda")
     noisy[5, 2, 3] = float("nan")
     iv1 = grid821.implied_vol(noisy, SPOT, variant)
-    fl1 = grid821.arb_check(iv1, noisy, SPOT, variant)
+    fl1 = grid821.arb_check(iv1, noisy, SPOT, oracle_variant(variant))
     iv2, fl2 = grid821.implied_vol_checked(noisy, SPOT, variant)
     assert torch.equal(torch.nan_to_num(iv1, nan=-1.0), torch.nan_to_num(iv2, nan=-1.0))
     assert torch.equal(fl1, fl2)
@@ -276,7 +307,7 @@ def test_fused_kernel_on_the_largest_lattice(afiv):
     ref_ratio = oracle.price_ratio_grid(p, logm, tau, R, Q)
     assert np.all(np.abs(ratio.cpu().numpy() - ref_ratio) <= price_tol(ref_ratio, p))
     iv_o = oracle.implied_vol_grid(ratio.cpu().numpy(), logm, tau, SPOT, R, Q, "A")
-    assert_iv_close(iv.cpu().numpy(), iv_o, logm, tau, SPOT, R, Q)
+    assert_iv_close(iv.cpu().numpy(), iv_o, logm, tau, SPOT, R, Q, same_path=False)
     flags_o = oracle.arb_check(iv.cpu().numpy(), ratio.cpu().numpy(), logm, tau, SPOT, R, Q, "A")
     assert np.array_equal(flags.cpu().numpy(), flags_o)
 
@@ -447,7 +478,7 @@ def test_stepped_exponential_on_evenly_spaced_exact_year_fractions(afiv):
     assert worst <= 2e-13, worst
 
 
-@pytest.mark.parametrize("variant", ["A", "B"])
+@pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
 def test_wave_per_surface_mode_equals_workgroup_per_surface_mode(afiv, grid821, variant):
     """Batches of 2048 surfaces or more take the wave-per-surface schedule, smaller ones the
     workgroup-per-surface schedule; a ragged batch (not a multiple of the surfaces in flight per
@@ -529,18 +560,48 @@ def test_half_strike_contraction_agrees_with_general_contraction(afiv):
     assert np.abs(a[:, :, keep] - b[:, :, keep]).max() <= 1e-14
 
 
-@pytest.mark.parametrize("variant", ["A", "B"])
+@pytest.mark.parametrize("variant", ["A_BRENT", "B"])
 def test_root_finder_follows_the_oracle_iteration_path(afiv, variant):
-    """Far inside the 1e-6 tolerance: the kernel makes brentq's decisions one for one, so it lands on
-    the oracle's root itself (agreement to 1e-10 on at least 99.9 % of a quarter of a million
+    """Far inside the 1e-6 tolerance: these kernels make brentq's decisions one for one, so they land
+    on the oracle's root itself (agreement to 1e-10 on at least 99.9 % of a quarter of a million
     points), not merely near it."""
     logm = np.linspace(-0.2, 0.2, 50)
     tau = np.round(np.linspace(30, 730, 20)) / 365.0
     grid = afiv.Grid(logm, tau, R, Q)
     ratio = grid.price(dev(sample_params(256, 77)))
     iv = grid.implied_vol(ratio, SPOT, variant).cpu().numpy()
-    ref = oracle.implied_vol_grid(ratio.cpu().numpy(), logm, tau, SPOT, R, Q, variant)
+    ref = oracle.implied_vol_grid(ratio.cpu().numpy(), logm, tau, SPOT, R, Q, oracle_variant(variant))
     assert_iv_close(iv, ref, logm, tau, SPOT, R, Q)
     both = ~np.isnan(iv) & ~np.isnan(ref)
     assert both.sum() > 200000
     assert np.mean(np.abs(iv - ref)[both] <= 1e-10) >= 0.999
+
+
+def test_householder_solver_against_brentq_on_the_benchmark_lattice(afiv):
+    """Variant A finds the root of the forward form's increasing objective with a closed-form guess
+    and Householder steps instead of brentq's path.  On a quarter of a million points of the
+    benchmark lattice: the NaN mask is the Brent kernel's bit for bit (both apply brentq's rules at
+    the bracket ends with one arithmetic), every well-conditioned vol is within the reference's
+    xtol = 1e-6 of the oracle's brentq -- within 5e-7 in fact: brentq stops up to 2.5e-7 short of
+    the converged root, this solver 3e-8 -- and the flag words equal the Brent kernel's."""
+    logm = np.linspace(-0.2, 0.2, 50)
+    tau = np.round(np.linspace(30, 730, 20)) / 365.0
+    grid = afiv.Grid(logm, tau, R, Q)
+    ratio = grid.price(dev(sample_params(256, 77)))
+    iv_t, fl_t = grid.implied_vol_checked(ratio, SPOT, "A")
+    iv_b, fl_b = grid.implied_vol_checked(ratio, SPOT, "A_BRENT")
+    assert torch.equal(torch.isnan(iv_t), torch.isnan(iv_b))
+    assert torch.equal(fl_t, fl_b)
+    iv = iv_t.cpu().numpy()
+    ref = oracle.implied_vol_grid(ratio.cpu().numpy(), logm, tau, SPOT, R, Q, "A")
+    assert_iv_close(iv, ref, logm, tau, SPOT, R, Q, same_path=False)
+    well = vega(ref, logm, tau, SPOT, R, Q) >= 1e-3
+    assert well.sum() > 200000
+    assert np.abs(iv - ref)[well].max() <= 5e-7
+    # its own residual: the Newton step left at the returned vol is below 1e-8 wherever the
+    # objective resolves it (vega * 1e-8 above the rounding of the price)
+    price, unit = reprice_a(iv, logm, tau, SPOT, R, Q)
+    target = ratio.cpu().numpy() * SPOT * np.exp(-R * tau)[None, :, None]
+    v = vega(iv, logm, tau, SPOT, R, Q)
+    m = ~np.isnan(iv) & (iv > 0.001) & (iv < 3.0)
+    assert np.all(np.abs(price - target)[m] <= 1.5e-8 * v[m] + unit[m])
