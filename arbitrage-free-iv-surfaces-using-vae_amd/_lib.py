@@ -46,6 +46,7 @@ SIGNATURES = {
                                          c_void_p]),
     "afiv_surface": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
+    "afiv_surface_static": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "afiv_decoder_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(DecoderWeights)]),
     "afiv_decoder_destroy": (c_int, [c_void_p]),
     "afiv_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p,

@@ -100,6 +100,12 @@ class Grid:
             raise ValueError(f"{what} must be [N,{self.nT},{self.nK}], got {tuple(t.shape)}")
         return t
 
+    def _flags(self, t: torch.Tensor, n: int) -> torch.Tensor:
+        t = _need(t, torch.int32, "flags_out", self.device)
+        if tuple(t.shape) != (n, 4):
+            raise ValueError(f"flags_out must be [{n},4], got {tuple(t.shape)}")
+        return t
+
     # -- entry points ----------------------------------------------------------------------
     def price(self, params: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """Price ratios C / exp(-r tau) for every (parameter set, maturity, strike): [N,nT,nK]."""
@@ -152,7 +158,7 @@ class Grid:
         n = ra.shape[0]
         iv = torch.empty_like(ra) if iv_out is None else self._lattice(iv_out, "iv_out")
         flags = torch.empty((n, 4), dtype=torch.int32, device=self.device) \
-            if flags_out is None else _need(flags_out, torch.int32, "flags_out", self.device)
+            if flags_out is None else self._flags(flags_out, n)
         with torch.cuda.device(self.device):
             rc = _lib.lib().afiv_implied_vol_checked(self._h, _ptr(ra), n, float(spot), VARIANTS[variant],
                                                      _ptr(iv), _ptr(flags), _stream())
@@ -171,7 +177,7 @@ class Grid:
         iv = torch.empty((n, self.nT, self.nK), dtype=torch.float64, device=self.device) \
             if iv_out is None else self._lattice(iv_out, "iv_out")
         flags = torch.empty((n, 4), dtype=torch.int32, device=self.device) \
-            if flags_out is None else _need(flags_out, torch.int32, "flags_out", self.device)
+            if flags_out is None else self._flags(flags_out, n)
         ratio = None
         if keep_ratio:
             ratio = torch.empty_like(iv) if ratio_out is None else self._lattice(ratio_out, "ratio_out")
@@ -180,6 +186,24 @@ class Grid:
                                          _ptr(ratio), _ptr(iv), _ptr(flags), _stream())
         _lib.check(rc, "afiv_surface")
         return iv, flags, ratio
+
+    def surface_static(self, params: torch.Tensor, spot: float, variant="A", *, iv_out: torch.Tensor,
+                       flags_out: torch.Tensor):
+        """``surface`` for callers that cannot allocate (see afiv_surface_static): outputs are the
+        caller's, the price ratios pass through a fixed array inside the library.  At most
+        ``STATIC_SCRATCH_DOUBLES // (nT * nK)`` surfaces per call; calls on one GPU must not overlap."""
+        p = self._params(params)
+        n = p.shape[0]
+        iv = self._lattice(iv_out, "iv_out")
+        flags = self._flags(flags_out, n)
+        if iv.shape[0] != n or iv.data_ptr() != iv_out.data_ptr() or flags.data_ptr() != flags_out.data_ptr() \
+                or p.data_ptr() != params.data_ptr():
+            raise ValueError("surface_static takes contiguous params [N,5], iv_out [N,nT,nK] and flags_out [N,4]")
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().afiv_surface_static(self._h, _ptr(p), n, float(spot), VARIANTS[variant],
+                                                _ptr(iv), _ptr(flags), _stream())
+        _lib.check(rc, "afiv_surface_static")
+        return iv, flags
 
     def arbitrage_penalty(self, params: torch.Tensor) -> torch.Tensor:
         """Device [2] doubles: sum and count of the static + butterfly penalties
@@ -239,6 +263,7 @@ class Grid:
 
 
 MAX_ENSEMBLE = 16384
+STATIC_SCRATCH_DOUBLES = 4 * 1024 * 1024
 
 
 def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torch.Tensor:

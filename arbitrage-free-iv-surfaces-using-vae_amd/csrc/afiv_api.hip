@@ -2,6 +2,7 @@
 // Creation calls allocate and fill device memory; execution calls only validate their
 // arguments and enqueue kernels on the caller's stream.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -11,9 +12,34 @@
 #include "afiv_internal.h"
 #include "laguerre144.inc"
 
+// Price ratios of afiv_surface_static pass through this array instead of caller or grid memory.
+// Every GPU the library runs on holds its own copy (32 MiB) at its own address until the process
+// ends.  In host code the name is only a handle for hipGetSymbolAddress: kernels are given the
+// address that call returns for the current device, never the name itself.
+static __device__ __align__(256) double scratch[AFIV_STATIC_SCRATCH_DOUBLES];
+
 namespace {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Device address of `scratch` on each GPU, resolved at the first afiv_surface_static call made with
+// that GPU current.  Racing first calls resolve the same address twice and store the same value.
+constexpr int MAX_DEVICES = 64;
+std::atomic<double *> scratch_addr[MAX_DEVICES];
+
+int scratch_for_current_device(double **out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AFIV_E_HIP;
+    if (dev < 0 || dev >= MAX_DEVICES) return AFIV_E_ARG;
+    double *p = scratch_addr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        if (hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return AFIV_E_HIP;
+        scratch_addr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return AFIV_OK;
+}
 
 int check_grid(const afiv_grid *g)
 {
@@ -39,6 +65,8 @@ const char *afiv_error_string(int code)
         case AFIV_E_HIP: return "HIP runtime call or kernel launch failed";
         case AFIV_E_ARG: return "bad argument (enum value, or object used on a different device)";
         case AFIV_E_WORKSPACE: return "grid was created without the workspace this call needs";
+        case AFIV_E_SCRATCH: return "batch exceeds the static scratch of afiv_surface_static "
+                                    "(N * nT * nK must not exceed AFIV_STATIC_SCRATCH_DOUBLES)";
         default: return "unknown error";
     }
 }
@@ -291,6 +319,25 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
                                          flags_out + 4 * off, s))) return rc;
     }
     return AFIV_OK;
+}
+
+int afiv_surface_static(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
+                        double *iv_out, int32_t *flags_out, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    if (N < 0) return AFIV_E_SHAPE;
+    if (variant < AFIV_VARIANT_A || variant > AFIV_VARIANT_A_BRENT) return AFIV_E_ARG;
+    if (N == 0) return AFIV_OK;
+    if (!params || !iv_out || !flags_out) return AFIV_E_NULL;
+    const int64_t per = (int64_t)g->v.nT * g->v.nK;
+    if (N > (int64_t)AFIV_STATIC_SCRATCH_DOUBLES / per) return AFIV_E_SCRATCH;
+    double *ratio = nullptr;
+    if ((rc = scratch_for_current_device(&ratio))) return rc;
+    hipStream_t s = as_stream(stream);
+    // every ratio the second kernel reads has been written by the first: nothing to clear
+    if ((rc = afiv_launch_price(g->v, params, N, ratio, s))) return rc;
+    return afiv_launch_surface_iv(g->v, ratio, N, spot, variant, iv_out, flags_out, s);
 }
 
 int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w)

@@ -15,10 +15,11 @@
  *     data (NaN implied vols, flag words), never errors, as in the reference's try/except -> NaN
  *     (generate_iv_surface_by_date.py:316-318).
  *   - All arrays are dense, row-major, in the shapes written next to each argument.
- *   - Concurrency: calls on different grid / decoder objects are independent.  The calls that
- *     invert vols (afiv_implied_vol, afiv_implied_vol_checked, afiv_surface) rewrite a small
- *     per-call table held inside the grid object (and afiv_surface with ratio_out == NULL the
- *     grid's workspace): issue them on one stream per grid object, or create one grid per stream.
+ *   - Concurrency: grid and decoder objects are immutable after creation and the library keeps no
+ *     other state, so calls may be issued from any thread on any stream, on shared objects too.
+ *     Two calls use scratch memory that is not the caller's and must therefore not overlap with
+ *     another call using the same scratch: afiv_surface with ratio_out == NULL (the grid's
+ *     workspace) and afiv_surface_static (one array per GPU).
  */
 #ifndef AFIV_H
 #define AFIV_H
@@ -37,7 +38,8 @@ enum {
     AFIV_E_SHAPE = -2,       /* a size is out of the supported range */
     AFIV_E_HIP = -3,         /* a HIP runtime call or kernel launch failed */
     AFIV_E_ARG = -4,         /* bad enum / flag value */
-    AFIV_E_WORKSPACE = -5    /* the call needs a workspace the grid was created without */
+    AFIV_E_WORKSPACE = -5,   /* the call needs a workspace the grid was created without */
+    AFIV_E_SCRATCH = -6      /* the batch exceeds the static scratch of afiv_surface_static */
 };
 
 /* Which Black-Scholes form is inverted / re-priced, and for the forward form how its root is
@@ -58,6 +60,7 @@ enum {
 #define AFIV_MAX_STRIKES 64      /* strikes per grid */
 #define AFIV_MAX_MATURITIES 64   /* maturities per grid */
 #define AFIV_MAX_ENSEMBLE 16384  /* surfaces per afiv_ensemble_stats call (one LDS-resident column) */
+#define AFIV_STATIC_SCRATCH_DOUBLES (4 * 1024 * 1024)   /* afiv_surface_static: N * nT * nK at most (32 MiB) */
 
 typedef struct afiv_grid afiv_grid;
 typedef struct afiv_decoder afiv_decoder;
@@ -133,6 +136,20 @@ int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N,
  * workspace-sized chunks); iv_out and flags_out are required. */
 int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
                  double *ratio_out, double *iv_out, int32_t *flags_out, void *stream);
+
+/* ---- whole surface, for callers that cannot allocate: afiv_surface with ratio_out == NULL, but
+ * the price ratios pass through a fixed 32 MiB array inside the library instead of a workspace the
+ * grid would have had to allocate, so neither the grid nor the caller provides memory for them and
+ * the call itself calls no hipMalloc / hipFree or allocating routine.  No counterpart in the
+ * reference: it exists for code under HIP graph capture, tight serving loops and harnesses that
+ * forbid allocation.  Same results as afiv_surface, bit for bit.
+ * N * nT * nK must not exceed AFIV_STATIC_SCRATCH_DOUBLES (4194 surfaces of 20 x 50, 24966 of
+ * 8 x 21), else AFIV_E_SCRATCH; larger batches are the caller's to split.  Every call on a GPU
+ * shares that GPU's array (each GPU holds its own copy until the process ends): calls that overlap
+ * on one GPU -- different streams or threads -- race on it, so issue them in one stream's order.
+ * Nothing in the array has to be cleared between calls. */
+int afiv_surface_static(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
+                        double *iv_out, int32_t *flags_out, void *stream);
 
 /* ---- decoder: replaces ConditionalVAE_SingleHeston.decode (cvae_model.py:145-160, decoder
  * stack :84-105 in eval mode) followed by the de-normalisation and exp/tanh transforms of

@@ -1,0 +1,62 @@
+"""afiv_surface_static (the entry point that allocates nothing: price ratios pass through a fixed
+array inside the library) against afiv_surface, through the C ABI: two calls in a row, the second
+on a smaller batch, must each equal afiv_surface bit for bit; a batch beyond the array is rejected."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SPOT, R, Q = 21000.0, 0.067, 0.0
+SCRATCH_DOUBLES = 4 * 1024 * 1024
+
+
+def _params(n, seed):
+    from test_gpu_parity import sample_params
+    return torch.as_tensor(sample_params(n, seed)).cuda()
+
+
+def _static(afiv, grid, p, variant):
+    n = p.shape[0]
+    iv = torch.full((n, grid.nT, grid.nK), -7.0, dtype=torch.float64, device="cuda")
+    fl = torch.full((n, 4), -7, dtype=torch.int32, device="cuda")
+    rc = afiv._lib.lib().afiv_surface_static(grid._h, ctypes.c_void_p(p.data_ptr()), n, SPOT, variant,
+                                            ctypes.c_void_p(iv.data_ptr()), ctypes.c_void_p(fl.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return rc, iv, fl
+
+
+def _same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_static_scratch_entry_point_equals_afiv_surface(afiv, variant):
+    logm = np.linspace(-0.2, 0.2, 50)
+    tau = np.round(np.linspace(30, 730, 20)) / 365.0
+    grid = afiv.Grid(logm, tau, R, Q)
+    for n, seed in ((3000, 5), (37, 6)):            # the second call reuses the array with a smaller batch
+        p = _params(n, seed)
+        rc, iv, fl = _static(afiv, grid, p, variant)
+        assert rc == 0
+        iv_ref, fl_ref, _ = grid.surface(p, SPOT, variant)
+        assert _same(iv, iv_ref) and torch.equal(fl, fl_ref)
+        assert (fl[:, 3] & 4).any()
+
+
+def test_static_scratch_entry_point_limits(afiv):
+    grid = afiv.Grid(np.linspace(-0.2, 0.2, 21), [0.25, 0.5, 1.0, 2.0], R, Q)
+    per = 4 * 21
+    most = SCRATCH_DOUBLES // per
+    p = _params(most + 1, 9)
+    rc, iv, fl = _static(afiv, grid, p, 0)
+    assert rc == -6 and "scratch" in afiv._lib.lib().afiv_error_string(rc).decode()
+    assert float(iv.max()) == -7.0                   # nothing was launched
+    rc, iv, fl = _static(afiv, grid, p[:most].contiguous(), 0)
+    assert rc == 0
+    iv_ref, fl_ref, _ = grid.surface(p[:most].contiguous(), SPOT, 0)
+    assert _same(iv, iv_ref) and torch.equal(fl, fl_ref)
+    rc, _, _ = _static(afiv, grid, p[:0].contiguous(), 0)
+    assert rc == 0
