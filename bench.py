@@ -1,38 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the surface-generation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (starts its own N ranks when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config {1,2,4}                      (the other BASELINE.json workloads, ms per call)
 
-A step = one pass of the hot path (Heston pricing -> implied vol -> arbitrage checks) over one
-batch of synthetic parameter sets already resident in HBM, on the workload the headline metric
-is quoted on: 50 strikes x 20 maturities, FP64 (BASELINE.json configs[2]; the per-GPU batch is
-1 048 576 / 8 surfaces so that eight GPUs process the configured 1 M surfaces per step).
-Surfaces are independent, so ranks hold disjoint row blocks (weak scaling) and the data path
-has no collective; at N > 1 the 16-byte flag words are all-gathered once per step.
+Headline (default): BASELINE.json configs[2] -- 1 048 576 synthetic Heston parameter sets x 50
+strikes x 20 maturities, FP64 pricing -> implied vol (variant A) -> static / calendar / butterfly
+checks.  A step = one pass of that path over the WHOLE 1 048 576-surface batch, inputs already
+resident in HBM; at N ranks each holds a contiguous block of 1 048 576 / N rows (strong scaling:
+the total is fixed).  The data path has no collective; a step ends with the all-gather of the flag
+words and of the implied vols (north-star: "only a final RCCL all-gather of surfaces and arb
+flags"), issued per chunk of rows on the collective's own stream while the next chunk computes.
 
-Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant kernel (pricing), timed
+Prints ONE JSON line (rank 0).  ``roofline`` describes the kernel that takes the most time, timed
 with events on the launch stream inside the timed region; ``cpu_baseline`` times the CPU oracle
 (test infrastructure, used here only as the measured baseline) on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import afiv_bootstrap  # noqa: E402
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X: half of the 157.3 TFLOP/s FP32 vector peak
 N_STRIKES, N_MATURITIES = 50, 20
 SPOT, R, Q = 21000.0, 0.067, 0.0
-SURFACES_PER_GPU = 131072          # x 8 GPUs = 1 048 576 surfaces per step
+TOTAL_SURFACES = 1048576           # BASELINE.json configs[2]
+GATHER_CHUNKS = 4                  # row chunks per rank whose all-gather overlaps the next chunk's kernels
 
 
 def pricing_flops(n_t: int, n_k: int) -> float:
@@ -44,8 +44,9 @@ def pricing_flops(n_t: int, n_k: int) -> float:
 
 
 def iv_checks_flops(n_t: int, n_k: int) -> float:
-    """Algorithmic FLOPs of the implied-vol + checks kernel per surface: 12 root-finder iterations
-    x 120 per point, plus 125 per point for the three checks."""
+    """Algorithmic FLOPs of the implied-vol + checks kernel per surface by the contract's count:
+    12 root-finder iterations x 120 per point, plus 125 per point for the three checks.  (The
+    variant-A kernel needs 2 evaluations, not 12: the count prices the reference's work.)"""
     return n_t * n_k * (1440.0 + 125.0)
 
 
@@ -53,9 +54,10 @@ def surface_flops(n_t: int, n_k: int) -> float:
     return pricing_flops(n_t, n_k) + iv_checks_flops(n_t, n_k)
 
 
-def synthetic_params(n: int, seed: int, device) -> torch.Tensor:
+def synthetic_params(n: int, seed: int, device):
     """BASELINE config 3 sampler: exp/tanh(param_mean + param_std * eps), eps ~ N(0,1) float32,
     clamped to the calibration bounds (run_single_heston_calibration.py:237-243)."""
+    import torch
     mean = torch.tensor([-0.2858, -4.4085, -3.7188, 1.1875, -3.7454])
     std = torch.tensor([1.6307, 1.4661, 2.1172, 1.4222, 1.1040])
     g = torch.Generator().manual_seed(seed)
@@ -69,50 +71,192 @@ def synthetic_params(n: int, seed: int, device) -> torch.Tensor:
 
 
 def grids():
+    import numpy as np
     logm = np.linspace(-0.2, 0.2, N_STRIKES)
     tau = np.round(np.linspace(30, 730, N_MATURITIES)) / 365.0
     return logm, tau
 
 
-def cpu_baseline(logm, tau, seconds_target: float = 20.0):
+def host_threads() -> int:
+    """Threads this process may use: its CPU affinity, capped by OMP_NUM_THREADS when the
+    environment sets one (a shared box exports its per-job share there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return max(n, 1)
+
+
+def cpu_baseline(logm, tau, seconds_each: float = 13.0):
     """Times the CPU oracle (one option at a time: 2 x 144-node quadrature per price, Brent per
-    implied vol, then the checks) on a bounded sample of the same workload."""
+    implied vol, then the checks -- the reference's per-point algorithm) on bounded samples of the
+    same workload: once on a single thread, once on every thread this job may use."""
     import oracle
-    threads = oracle.set_threads(min(16, os.cpu_count() or 1))
-    p = synthetic_params(2048, 3, "cpu").numpy()
+    p = synthetic_params(16384, 3, "cpu").numpy()
+
+    def leg(threads, rate_per_thread):
+        used = oracle.set_threads(threads)
+        n = int(min(len(p), max(used, used * round(seconds_each * rate_per_thread))))
+        n -= n % used
+        t0 = time.perf_counter()
+        oracle.surface_batch(p[:n], logm, tau, SPOT, R, Q, "A")
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "threads": used, "surfaces": n, "seconds": dt}
+
+    oracle.set_threads(1)
     t0 = time.perf_counter()
-    oracle.surface_batch(p[:threads], logm, tau, SPOT, R, Q, "A")
-    per_surface_cpu = (time.perf_counter() - t0)            # seconds of one core per surface
-    n = int(max(threads, min(2048, seconds_target / max(per_surface_cpu, 1e-6))))
-    n -= n % threads
-    t0 = time.perf_counter()
-    oracle.surface_batch(p[:n], logm, tau, SPOT, R, Q, "A")
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "surfaces/s", "cores": threads, "kind": "port",
-            "sample": f"{n} surfaces of the same 20x50 workload, C oracle "
-                      f"(per-option quadrature + Brent + checks), {dt:.1f} s wall"}
+    oracle.surface_batch(p[:8], logm, tau, SPOT, R, Q, "A")
+    rate = 8 / max(time.perf_counter() - t0, 1e-6)                 # surfaces per second of one thread
+    single = leg(1, rate)
+    full = leg(host_threads(), single["value"])
+    return {"value": full["value"], "unit": "surfaces/s", "cores": full["threads"], "kind": "port",
+            "sample": f"{full['surfaces']} surfaces of the same 20x50 workload in {full['seconds']:.1f} s on "
+                      f"{full['threads']} threads; C oracle = the reference's per-option algorithm "
+                      "(2 x 144-node quadrature per price, Brent per vol, checks)",
+            "single_thread": {"value": single["value"], "unit": "surfaces/s", "cores": 1,
+                              "sample": f"{single['surfaces']} surfaces in {single['seconds']:.1f} s"},
+            "host_cpu_count": os.cpu_count(), "threads_available_to_this_job": host_threads()}
 
 
+# ---------------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N starts N ranks itself, before anything touches a GPU
+# ---------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int) -> int:
+    port = free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+# ---------------------------------------------------------------------------------------------
+# other BASELINE.json workloads: milliseconds per call, not the headline
+# ---------------------------------------------------------------------------------------------
+def run_config(which: int, steps: int, warmup: int):
+    import numpy as np
+    import torch
+    import afiv_bootstrap
+    afiv = afiv_bootstrap.load()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    t_grid = np.array([0.08333333, 0.16666667, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+    lm_grid = np.linspace(-0.2, 0.2, 21)
+    grid = afiv.Grid(lm_grid, t_grid, R, Q, device=dev)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    if which in (1, 2):
+        d = np.load(os.path.join(ROOT, "tests", "golden", "decoder.npz"))
+        dec = afiv.Decoder({k: d[k] for k in d.files if k.startswith("decoder.")}, d["param_mean"], d["param_std"],
+                           device=dev)
+        dates, per_date = (1, 100) if which == 1 else (500, 100)
+        n = dates * per_date
+        g = torch.Generator().manual_seed(20251110)
+        z = torch.randn(n, 4, generator=g).to(dev)
+        # conditioning rows are z-scored in the reference's data: one row per date, repeated per sample
+        c = torch.randn(dates, 8, generator=g).repeat_interleave(per_date, 0).contiguous().to(dev)
+        iv = torch.empty((n, 8, 21), dtype=torch.float64, device=dev)
+        ratio = torch.empty_like(iv)
+        flags = torch.empty((n, 4), dtype=torch.int32, device=dev)
+
+        def call():
+            p64 = dec.decode(z, c, want=("params64",))["params64"]
+            grid.surface(p64, SPOT, "A", iv_out=iv, flags_out=flags, ratio_out=ratio)
+        ms = timed(call)
+        out = {"config": which, "workload": f"{dates} date(s) x {per_date} samples: decode -> price -> implied vol "
+               "-> checks on the reference's 8 x 21 lattice (synthetic z and conditioning rows, the "
+               "reference checkpoint's decoder weights)", "surfaces": n, "ms_per_call": ms,
+               "surfaces_per_s": n / ms * 1e3, "success_frac": float(((flags[:, 3] & 8) != 0).float().mean())}
+    elif which == 4:
+        cands, days = 4096, 500
+        params = synthetic_params(cands, 4, dev)
+        market = grid.price(synthetic_params(days, 5, dev))
+        market = market * (1.0 + 1e-3 * torch.randn(market.shape, generator=torch.Generator().manual_seed(6)).to(dev).double())
+        model = torch.empty((cands, 8, 21), dtype=torch.float64, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        box = {}
+
+        def call():
+            ev[0].record()
+            grid.price(params, out=model)
+            ev[1].record()
+            box["loss"] = grid.stage1_objective(model, params, market, 1.0)
+            ev[2].record()
+        ms = timed(call)
+        torch.cuda.synchronize()
+        loss = box["loss"]
+        out = {"config": 4, "workload": "calibration Stage-1 objective: 4096 candidate parameter sets priced once on "
+               "8 x 21, then the 4096 x 500 loss matrix against 500 synthetic market days", "ms_per_call": ms,
+               "price_ms": ev[0].elapsed_time(ev[1]), "loss_matrix_ms": ev[1].elapsed_time(ev[2]),
+               "losses_per_s": cands * days / ms * 1e3, "finite_frac": float(torch.isfinite(loss).float().mean()),
+               "guarded_frac": float((loss >= 1e10).float().mean())}
+    else:
+        raise SystemExit("--config takes 1, 2 or 4 (3 is the default headline run)")
+    out.update({"metric": "ms per call", "n_gpus": 1, "steps": steps, "warmup": warmup, "data": "synthetic",
+                "dtype": "f64"})
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# headline
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--surfaces-per-gpu", type=int, default=SURFACES_PER_GPU)
+    ap.add_argument("--surfaces", type=int, default=TOTAL_SURFACES,
+                    help="total surfaces per step over all ranks (default: the configured 1 048 576)")
+    ap.add_argument("--config", type=int, default=3, help="1, 2 or 4: time another BASELINE.json workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="leave vols and flags sharded (no collective at all)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the multi-rank path on a box with fewer GPUs than ranks "
-                         "(ranks share devices, the flag words are gathered through host memory)")
+                         "(ranks share devices, gathers go through host memory)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered flag words of the last step here (.npy)")
     args = ap.parse_args()
+
+    if args.config != 3:
+        return run_config(args.config, args.steps, args.warmup)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # the parent never touches a GPU
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import afiv_bootstrap
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
-                         "python -m torch.distributed.run --nproc-per-node N)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -125,117 +269,142 @@ def main():
     afiv = afiv_bootstrap.load()
     logm, tau = grids()
     grid = afiv.Grid(logm, tau, R, Q, device=device)
-    n_local = args.surfaces_per_gpu
-    params = synthetic_params(n_local, 3 + rank, device)
+    total = args.surfaces
+    lo, hi = afiv.dist.shard_bounds(total, world, rank)
+    n_local = hi - lo
+    if world > 1 and total % world:
+        raise SystemExit("--surfaces must divide by the number of ranks")
+    # one seeded draw of the whole batch, of which each rank keeps its rows: the union of the
+    # ranks' inputs is the same 1 048 576 rows whatever N is
+    params = synthetic_params(total, 3, "cpu")[lo:hi].contiguous().to(device)
     ratio = torch.empty((n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
     iv = torch.empty_like(ratio)
-    flags_all = torch.empty((world * n_local, 4), dtype=torch.int32, device=device) if world > 1 else None
-
     flags_local = torch.empty((n_local, 4), dtype=torch.int32, device=device)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    gather = world > 1 and not args.no_gather
+    chunks = GATHER_CHUNKS if gather and n_local % GATHER_CHUNKS == 0 else 1
+    rows = n_local // chunks
+    if gather:
+        # gathered per chunk: [chunk][rank][rows of that chunk]; row r of rank q's chunk c is surface
+        # q * n_local + c * rows + r of the batch
+        iv_all = torch.empty((chunks, world, rows, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
+        flags_all = torch.empty((chunks, world, rows, 4), dtype=torch.int32, device=device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * chunks + 1)] for _ in range(args.steps)]
 
     def step(events=None):
-        # the two launches afiv_surface makes, issued separately so that each can be timed
+        pending = []
+        for c in range(chunks):
+            sl = slice(c * rows, (c + 1) * rows)
+            if events:
+                events[2 * c].record()
+            grid.price(params[sl], out=ratio[sl])
+            if events:
+                events[2 * c + 1].record()
+            grid.implied_vol_checked(ratio[sl], SPOT, "A", iv_out=iv[sl], flags_out=flags_local[sl])
+            if gather and args.backend == "nccl":
+                # asynchronous: the collective waits for this chunk's kernels on its own stream
+                # while the next chunk's kernels are enqueued behind them on ours
+                pending.append(dist.all_gather_into_tensor(flags_all[c].view(world * rows, 4), flags_local[sl],
+                                                           async_op=True))
+                pending.append(dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES),
+                                                           iv[sl], async_op=True))
+            elif gather:
+                for dst, src in ((flags_all[c], flags_local[sl]), (iv_all[c], iv[sl])):
+                    host = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype)
+                    dist.all_gather_into_tensor(host, src.cpu())
+                    dst.copy_(host.view(dst.shape))
         if events:
-            events[0].record()
-        grid.price(params, out=ratio)
-        if events:
-            events[1].record()
-        grid.implied_vol_checked(ratio, SPOT, "A", iv_out=iv, flags_out=flags_local)
-        if events:
-            events[2].record()
+            events[2 * chunks].record()
+        for w in pending:
+            w.wait()
+
+    def fence():
+        torch.cuda.synchronize()
         if world > 1:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(flags_all, flags_local)
-            else:
-                host = flags_local.cpu()
-                gathered = torch.empty((world * n_local, 4), dtype=torch.int32)
-                dist.all_gather_into_tensor(gathered, host)
-                flags_all.copy_(gathered)
-        return flags_local
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        flags = step(ev[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        step(ev[i])
+    fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # The surfaces themselves stay sharded while the job runs; if one consumer wants them all, the
-    # vols are gathered ONCE at the end (not part of a step): time that exchange separately.
+    # what the exchange costs on its own (outside the timed steps): the same gathers, nothing to hide behind
     final_gather = None
-    if world > 1 and args.backend == "nccl":
-        try:
-            iv_all = torch.empty((world * n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
-            dist.all_gather_into_tensor(iv_all, iv)
-            torch.cuda.synchronize()
-            dist.barrier()
-            final_gather = {"what": "all-gather of the implied vols after the last step (outside the timed steps)",
-                            "bytes_per_rank": iv.numel() * 8, "ms": (time.perf_counter() - tg) * 1e3}
-            del iv_all
-        except Exception as exc:   # the headline number must not depend on this optional exchange
-            final_gather = {"error": repr(exc)}
+    if gather and args.backend == "nccl":
+        fence()
+        tg = time.perf_counter()
+        for c in range(chunks):
+            sl = slice(c * rows, (c + 1) * rows)
+            dist.all_gather_into_tensor(flags_all[c].view(world * rows, 4), flags_local[sl])
+            dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES), iv[sl])
+        fence()
+        final_gather = {"what": "all-gather of implied vols and flag words, alone; inside a step it overlaps the "
+                                "next chunk's kernels and is part of `value`",
+                        "bytes_per_rank": iv.numel() * 8 + flags_local.numel() * 4,
+                        "ms": (time.perf_counter() - tg) * 1e3}
+    elif gather:
+        final_gather = {"what": "gloo rehearsal: gathers go through host memory, not timed separately"}
 
-    k_price = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
-    k_iv = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
-
+    k_price = float(np.mean([sum(e[2 * c].elapsed_time(e[2 * c + 1]) for c in range(chunks)) for e in ev])) * 1e-3
+    k_iv = float(np.mean([sum(e[2 * c + 1].elapsed_time(e[2 * c + 2]) for c in range(chunks)) for e in ev])) * 1e-3
     if rank == 0:
-        total_surfaces = world * n_local * args.steps
-        value = total_surfaces / elapsed
-        achieved = pricing_flops(N_MATURITIES, N_STRIKES) * n_local / k_price / 1e12
-        fl = flags.cpu().numpy()
-        traffic = traffic_iv = None
+        value = total * args.steps / elapsed
+        fl = (flags_all.reshape(-1, 4) if gather else flags_local).cpu().numpy()
+        if args.dump:
+            if gather:       # back to batch order: surface = rank * n_local + chunk * rows + r
+                np.save(args.dump, flags_all.permute(1, 0, 2, 3).reshape(-1, 4).cpu().numpy())
+            else:
+                np.save(args.dump, fl)
+        pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            if pmc.get("surfaces_per_launch") == n_local:
-                traffic = pmc.get("price_kernel_hbm_bytes_per_launch")
-                traffic_iv = pmc.get("surface_kernel_hbm_bytes_per_launch")
+        per_launch = pmc.get("surfaces_per_launch")
+
+        def traffic(key):
+            # measured HBM bytes per launch, scaled to this run's surfaces per launch (traffic is
+            # proportional to the rows a launch processes)
+            v = pmc.get(key)
+            return None if not v or not per_launch else v * n_local / per_launch
+
+        def roof(name, flops, seconds, pipe, traffic_key):
+            achieved = flops * n_local / seconds / 1e12
+            return {"bound": "mfma", "pipe": pipe, "kernel": name, "achieved": achieved,
+                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                    "traffic": traffic(traffic_key), "flops_per_surface": flops,
+                    "kernel_ms_per_step": seconds * 1e3, "launches_per_step": chunks,
+                    "surfaces_per_launch": rows}
+        r_price = roof("price_kernel", pricing_flops(N_MATURITIES, N_STRIKES), k_price,
+                       "FP64 vector + v_mfma_f64 (same 78.6 TFLOP/s peak)", "price_kernel_hbm_bytes_per_launch")
+        r_iv = roof("iv_fast_kernel", iv_checks_flops(N_MATURITIES, N_STRIKES), k_iv,
+                    "FP64 vector (no matrix work in this kernel); FLOPs by the contract's count of 12 "
+                    "root-finder iterations per point, the kernel needs 2", "iv_fast_kernel_hbm_bytes_per_launch")
+        dominant, other = (r_price, r_iv) if k_price >= k_iv else (r_iv, r_price)
         out = {
             "metric": "arb-checked IV surfaces/sec", "value": value, "unit": "surfaces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic Heston parameter sets x 50 strikes x 20 maturities, "
-                                   "FP64 pricing + implied vol (variant A, Brent) + static/"
-                                   "calendar/butterfly checks (BASELINE.json configs[2])",
-                       "surfaces_per_gpu_per_step": n_local, "strikes": N_STRIKES,
+            "config": {"workload": "1 048 576 synthetic Heston parameter sets x 50 strikes x 20 maturities, "
+                                   "FP64 pricing + implied vol (variant A) + static/calendar/butterfly "
+                                   "checks (BASELINE.json configs[2])" if total == TOTAL_SURFACES else
+                                   f"REDUCED batch of {total} surfaces (not the configured 1 048 576) x 50 x 20",
+                       "surfaces_per_step": total, "surfaces_per_gpu_per_step": n_local, "strikes": N_STRIKES,
                        "maturities": N_MATURITIES, "spot": SPOT, "r": R, "q": Q,
-                       "parallelism": f"rows sharded over {world} rank(s), flags all-gather only"},
-            "roofline": {"bound": "mfma", "pipe": "FP64 vector + v_mfma_f64 (same 78.6 TFLOP/s peak)",
-                         "kernel": "price_kernel", "achieved": achieved,
-                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "flops_per_surface": pricing_flops(N_MATURITIES, N_STRIKES),
-                         "kernel_ms": {"price": k_price * 1e3, "implied_vol_and_checks": k_iv * 1e3},
-                         "note": "the kernel the utilisation target names (and the larger share of the "
-                                 "algorithmic FLOPs); by time the implied-vol kernel is the longer of the "
-                                 "two, its roofline follows"},
-            # the other kernel of a step, same conventions
-            "roofline_iv_checks": {"bound": "mfma", "pipe": "FP64 vector (no matrix work in this kernel)",
-                                   "kernel": "surface_kernel",
-                                   "achieved": iv_checks_flops(N_MATURITIES, N_STRIKES) * n_local / k_iv / 1e12,
-                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": iv_checks_flops(N_MATURITIES, N_STRIKES) * n_local / k_iv / 1e12
-                                   / FP64_VECTOR_PEAK_TFLOPS,
-                                   "traffic": traffic_iv,
-                                   "flops_per_surface": iv_checks_flops(N_MATURITIES, N_STRIKES)},
+                       "parallelism": f"rows sharded over {world} rank(s)" +
+                                      (f", vols + flags all-gathered per {rows}-row chunk, overlapped" if gather else
+                                       ", no collective")},
+            "roofline": dominant,
+            "roofline_other_kernel": other,
             "whole_path_tflops": surface_flops(N_MATURITIES, N_STRIKES) * value / 1e12,
             "check": {"valid_surfaces_frac": float(np.mean((fl[:, 3] & 4) != 0)),
                       "arbitrage_free_frac": float(np.mean((fl[:, 3] & 1) != 0)),

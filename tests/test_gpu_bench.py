@@ -1,0 +1,35 @@
+"""bench.py as a program: it starts its own ranks, and two ranks (sharing the one GPU of the test
+box, gathers through gloo) produce the flag words of a single-rank run, surface for surface."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(tmp_path, tag, *extra):
+    dump = str(tmp_path / f"{tag}.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--surfaces", "6144", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--dump", dump, *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    return line, np.load(dump)
+
+
+def test_two_self_launched_ranks_reproduce_the_single_rank_flags(tmp_path):
+    one, flags1 = _bench(tmp_path, "one", "--gpus", "1")
+    two, flags2 = _bench(tmp_path, "two", "--gpus", "2", "--backend", "gloo")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["config"]["surfaces_per_gpu_per_step"] == 6144 and two["config"]["surfaces_per_gpu_per_step"] == 3072
+    assert flags1.shape == flags2.shape == (6144, 4)
+    assert np.array_equal(flags1, flags2)
+    assert (flags1[:, 3] & 4).any() and not (flags1[:, 3] & 4).all()
+    for line in (one, two):
+        assert line["roofline"]["kernel"] in ("price_kernel", "iv_fast_kernel") and line["roofline"]["frac"] > 0
+        assert "REDUCED" in line["config"]["workload"]          # not the configured batch: says so

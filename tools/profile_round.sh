@@ -16,4 +16,5 @@ timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format cs
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o $TAG -- $S > $O/bench_write.json 2> $O/err_write.log
 cd $R
 python3 tools/pmc_summary.py $O/stats $O/pmc_sq $O/pmc_sq2 $O/pmc_fetch $O/pmc_write > $O/summary.json
+python3 tools/pmc_traffic.py $O/summary.json $O/bench_fetch.json > $O/pmc_traffic.json
 cat $O/bench_stats.json
