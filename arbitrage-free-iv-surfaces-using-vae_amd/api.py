@@ -290,7 +290,7 @@ def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torc
     return out
 
 
-MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5}
+MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5, "expm1": 6, "cosm1": 7}
 
 
 def debug_math(op: str, x: torch.Tensor, y: torch.Tensor | None = None):
@@ -299,14 +299,15 @@ def debug_math(op: str, x: torch.Tensor, y: torch.Tensor | None = None):
     if x.dtype != torch.float64 or not x.is_cuda:
         raise TypeError("x must be a CUDA float64 tensor")
     out0 = torch.empty_like(x)
-    out1 = torch.empty_like(x) if op == "sincos" else None
+    two = op in ("sincos", "expm1", "cosm1")
+    out1 = torch.empty_like(x) if two else None
     if y is not None:
         y = y.contiguous()
     with torch.cuda.device(x.device):
         rc = _lib.lib().afiv_debug_math(MATH_OPS[op], _ptr(x), _ptr(y), x.numel(), _ptr(out0), _ptr(out1),
                                         _stream())
     _lib.check(rc, "afiv_debug_math")
-    return (out0, out1) if op == "sincos" else out0
+    return (out0, out1) if two else out0
 
 
 _DEC_LINEAR = (0, 4, 8, 12)

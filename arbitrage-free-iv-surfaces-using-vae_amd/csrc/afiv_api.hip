@@ -462,7 +462,7 @@ int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double 
                     void *stream)
 {
     if (n < 0) return AFIV_E_SHAPE;
-    if (op < 0 || op > AFIV_MATH_NDTR) return AFIV_E_ARG;
+    if (op < 0 || op > AFIV_MATH_COSM1) return AFIV_E_ARG;
     if (n == 0) return AFIV_OK;
     if (!x || !out0) return AFIV_E_NULL;
     if (op == AFIV_MATH_ATAN2 && !y) return AFIV_E_NULL;

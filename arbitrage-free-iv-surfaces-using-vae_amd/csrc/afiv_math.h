@@ -101,6 +101,34 @@ __device__ __forceinline__ double exp_core_f64(double x)
     return __builtin_ldexp(p, (int)k);                          // v_ldexp_f64: exact scaling, graceful underflow
 }
 
+// exp(x) and exp(x) - 1 together: for |x| < log(2)/2 the reduction leaves k = 0 and the polynomial
+// itself is 1 + r q, so r q is exp(x) - 1 without the cancellation of subtracting 1 afterwards
+// (relative 2 ulp down to x -> 0); elsewhere the subtraction loses nothing.
+template <bool PINNED = true>
+__device__ __forceinline__ double exp_expm1_f64(double x, double *em1)
+{
+    const double k = __builtin_rint(x * AFIV_LOG2E);
+    double r = __builtin_fma(k, -AFIV_LN2_HI, x);
+    r = __builtin_fma(k, -AFIV_LN2_LO, r);
+    const coef_ptr c_exp = (PINNED ? coeffs(r) : coeffs_hoistable()) + OFF_EXP;
+    double p = c_exp[13];
+    p = fma_sc(p, r, c_exp[12]);
+    p = fma_sc(p, r, c_exp[11]);
+    p = fma_sc(p, r, c_exp[10]);
+    p = fma_sc(p, r, c_exp[9]);
+    p = fma_sc(p, r, c_exp[8]);
+    p = fma_sc(p, r, c_exp[7]);
+    p = fma_sc(p, r, c_exp[6]);
+    p = fma_sc(p, r, c_exp[5]);
+    p = fma_sc(p, r, c_exp[4]);
+    p = fma_sc(p, r, c_exp[3]);
+    p = fma_sc(p, r, c_exp[2]);
+    const double q = __builtin_fma(p, r, 1.0);
+    const double e = __builtin_ldexp(__builtin_fma(q, r, 1.0), (int)k);
+    *em1 = k == 0.0 ? q * r : e - 1.0;
+    return e;
+}
+
 // The same with the coefficients in caller-held registers: a kernel with scalar registers to
 // spare loads them once (load_exp_coef) instead of fetching them at every call.
 struct ExpCoef { double c[12]; };   // x^2 ... x^13
@@ -173,6 +201,34 @@ __device__ __forceinline__ void sincos_tab_f64(double x, const double *__restric
     const double dc = z * __builtin_fma(pc, z, -0.5);           // cos r - 1
     *s_out = __builtin_fma(t.x, dc, __builtin_fma(t.y, sr, t.x));
     *c_out = __builtin_fma(t.y, dc, __builtin_fma(-t.x, sr, t.y));
+}
+
+// sin, cos and cos - 1 of the same argument: the last one without the cancellation of subtracting
+// 1 from a cosine near 1 (the table entry is 1 there and the polynomial gives cos r - 1 directly).
+__device__ __forceinline__ void sincos_cm1_tab_f64(double x, const double *__restrict__ tab, double *s_out,
+                                                   double *c_out, double *cm1_out)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double shifted = __builtin_fma(x, AFIV_32_OVER_PI, 0x1.8p52);
+    const double k = shifted - 0x1.8p52;
+    double r = __builtin_fma(k, -AFIV_PIO32_1, x);
+    r = __builtin_fma(k, -AFIV_PIO32_2, r);
+    const int j = __double2loint(shifted) & 63;
+    const d2 t = reinterpret_cast<const d2 *>(tab)[j];
+    const double z = r * r;
+    const coef_ptr cs = coeffs(z) + OFF_SINT;
+    double ps = cs[2];
+    ps = fma_sc(ps, z, cs[1]);
+    ps = fma_sc(ps, z, cs[0]);
+    const double sr = __builtin_fma(r * z, ps, r);              // sin r
+    double pc = cs[5];
+    pc = fma_sc(pc, z, cs[4]);
+    pc = fma_sc(pc, z, cs[3]);
+    const double dc = z * __builtin_fma(pc, z, -0.5);           // cos r - 1
+    *s_out = __builtin_fma(t.x, dc, __builtin_fma(t.y, sr, t.x));
+    const double u = __builtin_fma(t.y, dc, -(t.x * sr));       // cos x - C
+    *c_out = t.y + u;
+    *cm1_out = (t.y - 1.0) + u;                                 // C - 1 is exact
 }
 
 // log(1 + f) through a 128-entry table in LDS.  u = fl(1 + f) = 2^k z with the high word of z in

@@ -220,10 +220,12 @@ int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int6
 /* ---- diagnostics: the kernels' own FP64 elementary functions, element-wise, so that unit tests
  * can check them against high-precision references.  No counterpart in the reference (which
  * calls libm / SciPy).  x, y, out0, out1: device [n]; y only for AFIV_MATH_ATAN2 (atan2(x, y));
- * out1 only for AFIV_MATH_SINCOS (out0 = sin, out1 = cos; may be NULL). */
+ * out1 only for AFIV_MATH_SINCOS (out0 = sin, out1 = cos), AFIV_MATH_EXPM1 and AFIV_MATH_COSM1; may be NULL. */
 enum {
     AFIV_MATH_EXP = 0, AFIV_MATH_SINCOS = 1, AFIV_MATH_LOG1P = 2, AFIV_MATH_ATAN2 = 3,
-    AFIV_MATH_RCP = 4, AFIV_MATH_NDTR = 5
+    AFIV_MATH_RCP = 4, AFIV_MATH_NDTR = 5,
+    AFIV_MATH_EXPM1 = 6,  /* out0 = exp(x) - 1, out1 = exp(x) */
+    AFIV_MATH_COSM1 = 7   /* out0 = cos(x) - 1, out1 = cos(x) */
 };
 int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
                     void *stream);

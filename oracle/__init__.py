@@ -227,6 +227,20 @@ def _market_points(iv_surface, t_grid, logm_grid, r, q):
     return np.array(all_lm), np.array(all_tau), np.array(all_pr)
 
 
+def _model_points(params, iv_surface, t_grid, logm_grid, r, q):
+    """The model price ratio at every valid market point, in _market_points' order: the same
+    per-point function as heston_model_ql.price_ratio, evaluated for the whole lattice in one call
+    of the C oracle instead of one call per point."""
+    full = price_ratio_grid(params, logm_grid, t_grid, r, q)[0]
+    out = []
+    for m in range(len(t_grid)):
+        row = iv_surface[m]
+        mask = ~np.isnan(row) & (row > 0) & (row < 2.0)
+        if mask.sum() >= 3:
+            out.extend(full[m][mask])
+    return np.array(out)
+
+
 def stage1_objective(params, iv_surface, t_grid, logm_grid, r=0.067, q=0.0,
                      drift_weight=1.0, model_pr=None, guard=True):
     """run_single_heston_calibration.py:252-287.  ``guard=False`` drops the NaN / negative-price
@@ -235,7 +249,7 @@ def stage1_objective(params, iv_surface, t_grid, logm_grid, r=0.067, q=0.0,
     kappa, theta, sigma_v, _rho, _v0 = params
     all_lm, all_tau, all_pr = _market_points(iv_surface, t_grid, logm_grid, r, q)
     if model_pr is None:
-        model_pr = np.array([price_ratio(params, lm, ta, r, q) for lm, ta in zip(all_lm, all_tau)])
+        model_pr = _model_points(params, iv_surface, np.asarray(t_grid, float), np.asarray(logm_grid, float), r, q)
     if guard and (np.any(np.isnan(model_pr)) or np.any(model_pr < 0)):
         return 1e10
     rmse = np.sqrt(np.mean((model_pr - all_pr) ** 2))
@@ -256,9 +270,9 @@ def density_wasserstein(params, lm, tau, market_pr, r, q, n_points=50, guard=Tru
     dlm = fine[1] - fine[0]
     md = np.zeros(n_points)
     dd = np.zeros(n_points)
-    for i in range(1, n_points - 1):
-        md[i] = np.exp(r * tau) * ((mkt[i + 1] - 2 * mkt[i] + mkt[i - 1]) / dlm ** 2)
-        dd[i] = np.exp(r * tau) * ((mdl[i + 1] - 2 * mdl[i] + mdl[i - 1]) / dlm ** 2)
+    # the reference's loop over i = 1 .. n_points - 2 (:127-131), element by element in one expression
+    md[1:-1] = np.exp(r * tau) * ((mkt[2:] - 2 * mkt[1:-1] + mkt[:-2]) / dlm ** 2)
+    dd[1:-1] = np.exp(r * tau) * ((mdl[2:] - 2 * mdl[1:-1] + mdl[:-2]) / dlm ** 2)
     md = np.maximum(md, 0)
     dd = np.maximum(dd, 0)
     if md.sum() < 1e-10 or dd.sum() < 1e-10:

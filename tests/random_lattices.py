@@ -49,22 +49,47 @@ def make_case(seed):
                 desc=f"nK={nK} kind={kind} nT={nT} tk={tk} r={r} q={q} spot={spot} {variant} trunc={trunc} N={N}")
 
 
-def price_bad(got, ref, p, tau):
-    """Points whose price leaves the allowance.  The oracle follows the reference formula
-    operation by operation; its rounding noise grows as eps kappa theta T / sigma_v^2 on top of
-    eps / sigma_v^2 (a 50-digit evaluation of the corner rows kappa = 20, theta = 2, sigma_v = 1e-3
-    puts the kernel within an ulp and the oracle 1e-7 away), so the allowance scales with it.
-    At sigma_v = 1e-5 the reference switches to its series form, which returns values of 1e60 and
-    more for some rows: there both sides agree to 5-7 digits and the rule is relative; where it
-    overflows, the per-option sum of the oracle gives +-inf and the kernel's contraction (inf - inf)
-    NaN, and either inverts to a NaN vol."""
-    noise = 32 * np.finfo(float).eps / p[:, 2, None, None] ** 2 * \
+def oracle_noise(p, tau):
+    """Rounding noise of ANY double-precision evaluation of the reference formula as written (the
+    oracle's included): it divides two quantities that are each within sigma_v^2 of a cancellation
+    by sigma_v^2, which costs eps / sigma_v^2, times kappa theta T for the drift term
+    (tests/test_oracle.py::test_oracle_noise_against_60_digit_corner_rows measures it)."""
+    return 32 * np.finfo(float).eps / np.maximum(p[:, 2, None, None], 1e-300) ** 2 * \
         np.maximum(1.0, (p[:, 0] * p[:, 1])[:, None, None] * np.abs(tau)[None, :, None])
-    series = (p[:, 2] <= 1e-5)[:, None, None]                  # the reference's series form: 5-7 digits
-    tol = price_tol(ref) + noise + 1e-4 * np.abs(ref) * ((np.abs(ref) > 10.0) | series)
+
+
+def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_points=12):
+    """Points whose price leaves the allowance.  The kernel is held to the PLAIN rule
+    1e-8 max(|C|, 1e-4) everywhere.  Where the oracle can arbitrate -- its own rounding noise
+    (oracle_noise) is below a tenth of that -- it does.  Elsewhere (small sigma_v with large
+    kappa theta T, and the series form the reference takes at sigma_v <= 1e-5) the oracle is the
+    noisy side: the kernel is compared with a 60-digit evaluation of the same quadrature
+    (oracle/exact.py) at up to ``max_exact_points`` of those points, still by the plain rule, and
+    with the oracle only by the oracle's own noise bound.  Where the formula's value leaves the
+    double range both sides must agree on that."""
+    from oracle import exact
+    tol = price_tol(ref)
+    noise = oracle_noise(p, tau) + 1e-4 * np.abs(ref) * (p[:, 2] <= 1e-5)[:, None, None]
     wild = lambda a: ~np.isfinite(a) | (np.abs(a) > 1e300)     # overflowed, or one doubling away from it
+    arbitrates = (noise <= 0.1 * tol) & ~wild(ref)
     with np.errstate(invalid="ignore"):
-        return ~(np.abs(got - ref) <= tol) & ~(wild(got) & wild(ref))
+        bad = arbitrates & ~(np.abs(got - ref) <= tol)
+        # the noisy remainder: a sanity bound against the oracle ...
+        bad |= ~arbitrates & ~(np.abs(got - ref) <= tol + noise) & ~(wild(got) & wild(ref))
+    # ... and the plain rule against the exact value at a sample of those points
+    idx = np.argwhere(~arbitrates)
+    if len(idx):
+        pick = idx[np.random.default_rng(len(idx)).permutation(len(idx))[:max_exact_points]]
+        ex = exact.price_ratio_points(p, logm, tau, [tuple(i) for i in pick], r, q, trunc)
+        for (i, t, k), e in zip(pick, ex):
+            g = got[i, t, k]
+            if wild(np.array(e)):
+                ok = bool(wild(np.array(g)))
+            else:
+                ok = abs(g - e) <= 1e-8 * max(abs(e), 1e-4)
+            if not ok:
+                bad[i, t, k] = True
+    return bad
 
 
 def run_case(afiv, c):
@@ -72,7 +97,7 @@ def run_case(afiv, c):
     g = afiv.Grid(logm, tau, r, q, trunc_days=c["trunc"])
     ref = oracle.price_ratio_grid(p, logm, tau, r, q, c["trunc"])
     got = g.price(dev(p)).cpu().numpy()
-    bad = price_bad(got, ref, p, tau)
+    bad = price_bad(got, ref, p, tau, logm, r, q, c["trunc"])
     assert not bad.any(), f"price: {bad.sum()} points, worst {np.nanmax(np.abs(got - ref)[bad]):.3g}"
     iv, fl = g.implied_vol_checked(dev(ref), spot, v)
     iv, fl = iv.cpu().numpy(), fl.cpu().numpy()

@@ -13,7 +13,7 @@ def run(afiv, op, x, y=None):
     xd = torch.tensor(x, dtype=torch.float64, device="cuda")
     yd = None if y is None else torch.tensor(y, dtype=torch.float64, device="cuda")
     out = afiv.debug_math(op, xd, yd)
-    if op == "sincos":
+    if op in ("sincos", "expm1", "cosm1"):
         return out[0].cpu().numpy(), out[1].cpu().numpy()
     return out.cpu().numpy()
 
@@ -33,6 +33,28 @@ def test_exp(afiv):
     edge = run(afiv, "exp", np.array([-1e300, -800.0, 800.0, np.inf, -np.inf, np.nan]))
     assert edge[0] == 0 and edge[1] == 0 and np.isinf(edge[2]) and np.isinf(edge[3]) and edge[4] == 0
     assert np.isnan(edge[5])
+
+
+def test_expm1_and_cosm1_keep_relative_accuracy_near_zero(afiv):
+    """exp(x) - 1 and cos(x) - 1 as the pricing kernel forms 1 - exp(-d T): relative accuracy down to
+    arguments of 1e-300, where subtracting 1 afterwards would leave nothing."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-30, 30, 2000), rng.uniform(-0.4, 0.4, 2000),
+                        10.0 ** rng.uniform(-300, -1, 2000) * rng.choice([-1.0, 1.0], 2000), [0.34, -0.34, 0.35, -0.35]])
+    em1, e = run(afiv, "expm1", x)
+    assert relerr(em1, [mp.expm1(mp.mpf(float(v))) for v in x]).max() <= 4 * EPS
+    assert relerr(e, [mp.exp(mp.mpf(float(v))) for v in x]).max() <= 3 * EPS
+    y = np.concatenate([rng.uniform(-10, 10, 2000), rng.uniform(-0.06, 0.06, 2000),
+                        10.0 ** rng.uniform(-150, -1, 2000) * rng.choice([-1.0, 1.0], 2000),
+                        rng.uniform(-6000, 6000, 1000)])
+    cm1, c = run(afiv, "cosm1", y)
+    ref = [-2 * mp.sin(mp.mpf(float(v)) / 2) ** 2 for v in y]            # cos - 1 without cancellation
+    # relative where the cosine is within 2^-8 of 1 (the table's first bin), absolute elsewhere
+    near = np.abs(np.remainder(y + np.pi / 64, 2 * np.pi) - np.pi / 64) < np.pi / 64
+    near &= np.abs(y) < 0.049
+    assert relerr(cm1[near], [r for r, k in zip(ref, near) if k]).max() <= 4 * EPS
+    assert np.max(np.abs(np.array([float(mp.mpf(float(g)) - r) for g, r in zip(cm1, ref)]))) <= 4e-16
+    assert np.max(np.abs(np.array([float(mp.mpf(float(g)) - mp.cos(mp.mpf(float(v)))) for g, v in zip(c, y)]))) <= 3e-16
 
 
 def test_sincos_absolute_accuracy(afiv):

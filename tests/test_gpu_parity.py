@@ -419,6 +419,27 @@ def test_price_against_50_digit_quadrature_at_small_vol_of_vol(afiv, golden_dir)
     assert np.abs(orc - ref).max() > 100 * np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("trunc", [True, False])
+def test_price_against_60_digit_quadrature_at_the_corners_and_on_the_series_branch(afiv, golden_dir, trunc):
+    """The PLAIN rule 1e-8 max(|C|, 1e-4) -- no sigma_v or kappa theta T allowance -- against the
+    exactly evaluated reference formula (tests/golden/make_exact_prices.py corners): (a) the corner
+    rows of the calibration box where a double-precision evaluation of the formula as written is
+    noisiest, kappa in {2, 20}, theta in {0.25, 2}, sigma_v in {1e-4, 1e-3}, |rho| up to 0.999,
+    maturities of 7 days, 0.9 and 5 years (the oracle is up to 4e-5 off there); (b) the series form
+    the reference switches to at sigma_v <= 1e-5, evaluated as written, including sigma_v = 0 where
+    it divides 0 by 0 (NaN on both sides)."""
+    g = np.load(f"{golden_dir}/exact_prices_corners.npz")
+    ref = g["ratio_trunc"] if trunc else g["ratio_exact_tau"]
+    grid = afiv.Grid(g["logm"], g["tau"], float(g["r"]), float(g["q"]), trunc_days=trunc)
+    got = grid.price(dev(g["params"])).cpu().numpy()
+    fin = np.isfinite(ref)
+    assert fin[: int(g["n_main"])].all() and fin.mean() > 0.85
+    assert np.array_equal(np.isfinite(got), fin)
+    err = np.abs(got - ref)[fin] / price_tol(ref[fin])
+    assert err.max() <= 1.0, f"max excess {err.max():.3g}"
+    print(f"trunc={trunc}: max |d| / tol = {err.max():.3g}, max |d| = {np.abs(got - ref)[fin].max():.3g}")
+
+
 @pytest.mark.parametrize("days,stepped", [
     ([30, 60, 90, 120, 150, 180], 1),                      # one increment: one step factor
     ([30, 67, 104, 141, 177, 214, 250, 288, 325], 2),      # 36..38 days: base step plus one-day factors

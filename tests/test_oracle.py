@@ -23,27 +23,39 @@ def pin(golden_dir):
 
 def test_pricing_restatement_reproduces_stored_quantlib_objectives(pin):
     """fit_error = Stage-2 objective (run_single_heston_calibration.py:342-406) or, on fallback,
-    the Stage-1 objective (:428-435), evaluated by QuantLib when the reference was run.
+    the Stage-1 objective (:428-435), evaluated by QuantLib when the reference was run.  All 500
+    stored days, split by what each day can show:
 
-    Expected agreement (every 4th day, 125 days): about half of the days to 1e-12 and three
-    quarters to 1e-9.  The rest are explained by (a) deep out-of-the-money prices of ~1e-17
-    whose rounding-noise SIGN trips the `< 0` guard differently (checked with the guard
-    removed), (b) the 1/dlm^2 = 1.5e4 amplification of price noise inside the density
-    Wasserstein term, (c) the 5 failed days that carry the previous day's parameters."""
+    * Stage-1 days -- the stored value is reproduced by the Stage-1 objective (168 prices, RMSE +
+      drift + Feller term, no density term) and not by Stage 2: at least 25 days, every one of them
+      to 1e-9.  A 1e-9 coincidence on a number of size 1e-2 does not happen by chance, so these
+      days pin the price restatement with no amplification in between.
+    * Stage-2 days whose `< 0` guard (:270-271) does not trip here: 55 % to 1e-12, 75 % to 1e-9,
+      92 % to 1e-6; of those with a calibrated vol-of-vol below 0.01 (a third of them) 99 % to
+      1e-9.  The remainder differs by up to 5e-3 of the density-Wasserstein term, which divides
+      second differences of prices by dlm^2 = 1/1.5e4 and clips them at zero.
+    * days whose guard trips here but did not in QuantLib (deep out-of-the-money prices of 1e-17
+      carry a rounding-noise sign; 55 days) and the 5 days that carry the previous day's
+      parameters (:537-549) are counted, not judged."""
     r, q = float(pin["r"]), float(pin["q"])
-    idx = np.arange(0, 500, 4)
-    err = []
-    for i in idx:
+    e1, e2, trip = [], [], []
+    for i in range(500):
         args = (pin["params"][i], pin["iv_surfaces"][i], pin["T_grid"], pin["logm_grid"], r, q)
-        s2 = oracle.stage2_objective(*args, guard=False)
-        s1 = oracle.stage1_objective(*args, guard=False)
-        err.append(min(abs(s2 - pin["fit_errors"][i]), abs(s1 - pin["fit_errors"][i])))
-    err = np.array(err)
-    ok = ~pin["failed"][idx]
-    assert np.mean(err[ok] <= 1e-12) >= 0.45
-    assert np.mean(err[ok] <= 1e-9) >= 0.65
-    assert np.mean(err[ok] <= 1e-6) >= 0.80
-    assert np.median(err[ok]) <= 1e-11
+        e1.append(abs(oracle.stage1_objective(*args, guard=False) - pin["fit_errors"][i]))
+        e2.append(abs(oracle.stage2_objective(*args, guard=False) - pin["fit_errors"][i]))
+        trip.append(oracle.stage1_objective(*args) >= 1e10)
+    e1, e2, trip = np.array(e1), np.array(e2), np.array(trip)
+    ok = ~pin["failed"]
+    stage1_day = ok & (e1 <= 1e-9) & (e2 > 1e-9)
+    assert stage1_day.sum() >= 25
+    stage2_day = ok & ~stage1_day & ~trip
+    assert stage2_day.sum() >= 400
+    e = e2[stage2_day]
+    assert np.mean(e <= 1e-12) >= 0.55 and np.mean(e <= 1e-9) >= 0.75 and np.mean(e <= 1e-6) >= 0.92
+    assert np.median(e) <= 1e-12
+    calm = stage2_day & (pin["params"][:, 2] < 0.01)
+    assert calm.sum() >= 150 and np.mean(e2[calm] <= 1e-9) >= 0.99
+    assert 40 <= (ok & trip).sum() <= 90 and (~ok).sum() == 5
 
 
 def test_guarded_objective_matches_on_days_without_noise_sign_flips(pin):
@@ -189,3 +201,30 @@ def test_oracle_noise_against_50_digit_quadrature(golden_dir):
     assert np.abs(got - ref)[small].max() > 1e-12           # the plain bound alone would not hold
     wide = g["params"][:, 2] >= 0.03
     assert np.abs(got - ref)[wide].max() < 1e-12
+
+
+def test_oracle_noise_against_60_digit_corner_rows(golden_dir):
+    """At the corners of the calibration box the same conditioning grows with the drift term:
+    the oracle (the reference formula evaluated in doubles as written) is within
+    32 eps max(1, kappa theta T) / sigma_v^2 of the exactly evaluated quadrature -- up to 4e-5 at
+    sigma_v = 1e-4 -- which is the allowance tests/random_lattices.py gives the ORACLE there; the GPU
+    kernel is held to the plain 1e-8 rule against the exact values
+    (tests/test_gpu_parity.py::test_price_against_60_digit_quadrature_at_the_corners_and_on_the_series_branch).
+    The series form the reference takes at sigma_v <= 1e-5 has no such cancellation: the oracle
+    reproduces its exact value to 1e-11, and returns NaN with it at sigma_v = 0 (0 / 0 as written)."""
+    g = np.load(f"{golden_dir}/exact_prices_corners.npz")
+    p, tau, n_main = g["params"], g["tau"], int(g["n_main"])
+    eps = np.finfo(float).eps
+    for trunc, key in ((True, "ratio_trunc"), (False, "ratio_exact_tau")):
+        ref = g[key]
+        got = oracle.price_ratio_grid(p, g["logm"], tau, float(g["r"]), float(g["q"]), trunc)
+        main = slice(0, n_main)
+        noise = 32 * eps / p[main, 2, None, None] ** 2 * np.maximum(1.0, (p[main, 0] * p[main, 1])[:, None, None] * tau[None, :, None])
+        err = np.abs(got - ref)[main]
+        assert np.all(err <= 1e-8 * np.maximum(np.abs(ref[main]), 1e-4) + noise)
+        assert err.max() > 1e-6                                  # far outside the plain rule: the oracle cannot arbitrate here
+        ser = slice(n_main, None)
+        fin = np.isfinite(ref[ser])
+        assert np.array_equal(np.isfinite(got[ser]), fin)
+        assert np.all(np.abs(got[ser] - ref[ser])[fin] <= 1e-11)
+        assert not fin[p[ser, 2] == 0.0].any() and fin[p[ser, 2] > 0.0].all()

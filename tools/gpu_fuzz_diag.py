@@ -16,7 +16,7 @@ for seed in seeds:
     g = afiv.Grid(c["logm"], c["tau"], c["r"], c["q"], trunc_days=c["trunc"])
     ref = oracle.price_ratio_grid(p, c["logm"], c["tau"], c["r"], c["q"], c["trunc"])
     got = g.price(dev(p)).cpu().numpy()
-    bad = ns["price_bad"](got, ref, p, c["tau"])
+    bad = ns["price_bad"](got, ref, p, c["tau"], c["logm"], c["r"], c["q"], c["trunc"])
     ex = np.abs(got - ref) * bad
     print(f"seed {seed}: {c['desc']}")
     one = np.isnan(got) != np.isnan(ref)
