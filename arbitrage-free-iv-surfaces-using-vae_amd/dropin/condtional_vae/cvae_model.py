@@ -76,8 +76,7 @@ class ConditionalVAE_SingleHeston(nn.Module):
         self.decoder = nn.Sequential(*_stack([latent_dim + conditioning_dim] + hidden[::-1],
                                              self.decoder_act, dropout),
                                      nn.Linear(hidden[0], param_dim))
-        self._hip_decoder = None
-        self._hip_decoder_key = None
+        self._hip_decoders = {}      # (device, weight versions, de-normalisation constants) -> afiv.Decoder
 
     def _get_activation(self, name):
         try:
@@ -102,17 +101,55 @@ class ConditionalVAE_SingleHeston(nn.Module):
         return (shapes == [(32, 12), (64, 32), (128, 64), (5, 128)]
                 and self._decoder_activation_name == "relu")
 
-    def _decoder_handle(self, device):
+    def _decoder_handle(self, device, param_mean=None, param_std=None):
+        """The device-side copy of the decoder weights, rebuilt when a weight, the device or the
+        de-normalisation constants change.  Layers are collected by type, not by position: with
+        ``dropout=0`` the reference's Sequential has no Dropout modules and its indices shift."""
         versions = tuple(p._version for p in self.decoder.parameters()) + \
             tuple(b._version for b in self.decoder.buffers())
-        key = (str(device), versions)
-        if self._hip_decoder is None or self._hip_decoder_key != key:
-            sd = {"decoder." + k: v for k, v in self.decoder.state_dict().items()}
-            zeros, ones = np.zeros(5, np.float32), np.ones(5, np.float32)
-            eps = next(m.eps for m in self.decoder if isinstance(m, nn.BatchNorm1d))
-            self._hip_decoder = _afiv.Decoder(sd, zeros, ones, bn_eps=eps, device=device)
-            self._hip_decoder_key = key
-        return self._hip_decoder
+        mean = np.zeros(5, np.float32) if param_mean is None else \
+            np.asarray(torch.as_tensor(param_mean).detach().cpu(), dtype=np.float32).reshape(5)
+        std = np.ones(5, np.float32) if param_std is None else \
+            np.asarray(torch.as_tensor(param_std).detach().cpu(), dtype=np.float32).reshape(5)
+        key = (str(device), versions, mean.tobytes(), std.tobytes())
+        if key not in self._hip_decoders:
+            if len(self._hip_decoders) >= 4:         # stale weight versions / other constants
+                self._hip_decoders.clear()
+            linear = [m for m in self.decoder if isinstance(m, nn.Linear)]
+            norms = [m for m in self.decoder if isinstance(m, nn.BatchNorm1d)]
+            sd = {}
+            for idx, m in zip((0, 4, 8, 12), linear):            # the checkpoint layout afiv.Decoder reads
+                sd[f"decoder.{idx}.weight"], sd[f"decoder.{idx}.bias"] = m.weight, m.bias
+            for idx, m in zip((1, 5, 9), norms):
+                sd[f"decoder.{idx}.weight"], sd[f"decoder.{idx}.bias"] = m.weight, m.bias
+                sd[f"decoder.{idx}.running_mean"], sd[f"decoder.{idx}.running_var"] = m.running_mean, m.running_var
+            self._hip_decoders[key] = _afiv.Decoder(sd, mean, std, bn_eps=norms[0].eps, device=device)
+        return self._hip_decoders[key]
+
+    def _inference_inputs(self, z, c):
+        """Inputs of an inference-mode decode on the model's GPU.  CPU tensors (the reference's
+        ``sample(n, c)`` default) are moved there; a model that itself lives on the CPU is an
+        error: the decoder kernel has no CPU fallback."""
+        where = next(self.decoder.parameters()).device
+        if z.is_cuda:
+            where = z.device
+        if where.type != "cuda":
+            raise RuntimeError("decode in inference mode runs the HIP decoder kernel and needs the model "
+                               "or its inputs on a GPU (no CPU fallback); call model.to('cuda')")
+        if not self._hip_ready():
+            raise RuntimeError("the HIP decoder implements hidden_dims=[128, 64, 32] with ReLU only")
+        return where, z.to(where).float().contiguous(), c.to(where).float().contiguous()
+
+    def decode_parameters(self, z, c, param_mean, param_std):
+        """decode followed by the de-normalisation and exp / tanh transforms of
+        generate_iv_surface_by_date.py:441-446, fused in the decoder kernel.  Returns
+        (params float32 [N,5], the same values widened to float64 [N,5]) on the GPU -- the second
+        is what the pricing kernel takes, as the reference's ``float(x)`` widening at :286."""
+        with torch.no_grad():
+            where, zf, cf = self._inference_inputs(z, c)
+            dec = self._decoder_handle(where, param_mean, param_std)
+            out = dec.decode(zf, cf, want=("params32", "params64"))
+        return out["params32"], out["params64"]
 
     def decode(self, z, c):
         """(z, c) -> normalised parameters (cvae_model.py:145-160)."""
@@ -121,14 +158,9 @@ class ConditionalVAE_SingleHeston(nn.Module):
             or any(p.requires_grad for p in self.decoder.parameters()))
         if self.training or needs_graph:
             return self.decoder(torch.cat([z, c], dim=1))          # autograd / batch statistics
-        if not z.is_cuda:
-            raise RuntimeError("decode in inference mode runs the HIP decoder kernel and needs CUDA "
-                               "tensors (no CPU fallback); move the model and inputs to the GPU")
-        if not self._hip_ready():
-            raise RuntimeError("the HIP decoder implements hidden_dims=[128, 64, 32] with ReLU only")
-        dec = self._decoder_handle(z.device)
-        out = dec.decode(z.float(), c.to(z.device).float(), want=("normalized",))
-        return out["normalized"].to(z.dtype)
+        where, zf, cf = self._inference_inputs(z, c)
+        out = self._decoder_handle(where).decode(zf, cf, want=("normalized",))
+        return out["normalized"].to(device=z.device, dtype=z.dtype)
 
     def forward(self, x, c):
         mu, logvar = self.encode(x, c)
@@ -178,7 +210,9 @@ class ConditionalVAE_SingleHeston(nn.Module):
 
     # ---- sampling --------------------------------------------------------------------------
     def sample(self, num_samples, conditioning, device="cpu"):
-        """z ~ N(0, I), one conditioning row broadcast if needed (cvae_model.py:347-373)."""
+        """z ~ N(0, I), one conditioning row broadcast if needed (cvae_model.py:347-373).  With the
+        reference's default ``device="cpu"`` the draw and the result are CPU tensors; the decoder
+        itself runs on the model's GPU (see ``_inference_inputs``)."""
         with torch.no_grad():
             z = torch.randn(num_samples, self.latent_dim).to(device)
             if conditioning.shape[0] == 1 and num_samples > 1:

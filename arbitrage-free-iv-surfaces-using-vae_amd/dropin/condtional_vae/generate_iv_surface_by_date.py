@@ -76,15 +76,10 @@ def generate_iv_surface(params, T_grid, logm_grid, spot, r, q):
 
 
 def decode_parameters(model, z, conditioning_batch, param_mean, param_std):
-    """decode -> de-normalise -> exp / tanh (:438-448) on the GPU; returns float32 [N,5]."""
-    with torch.no_grad():
-        normalized = model.decode(z, conditioning_batch)
-        t = normalized * param_std + param_mean
-        p = t.clone()
-        for idx in (0, 1, 2, 4):
-            p[:, idx] = torch.exp(t[:, idx])
-        p[:, 3] = torch.tanh(t[:, 3])
-    return p
+    """decode -> de-normalise -> exp / tanh (:438-448) in one kernel on the GPU.  Returns the
+    float32 parameters [N,5] the reference stores and the same values widened to float64, both on
+    the device: the second goes straight into the pricing kernel."""
+    return model.decode_parameters(z, conditioning_batch, param_mean, param_std)
 
 
 def ensemble_statistics(surfaces):
@@ -177,11 +172,12 @@ def main(argv=None):
     if args.seed is not None:
         gen = torch.Generator().manual_seed(args.seed)
     z = torch.randn(args.n_samples, 4, generator=gen).to(DEVICE)
-    params_np = decode_parameters(model, z, conditioning_batch, param_mean, param_std).cpu().numpy()
+    params32, params64 = decode_parameters(model, z, conditioning_batch, param_mean, param_std)
+    params_np = params32.cpu().numpy()               # only for the saved file: the path stays on the device
     print(f" Generated {len(params_np)} parameter sets")
 
     print("\nGenerating IV surfaces...")
-    iv, success = generate_iv_surfaces(params_np, T_GRID, LOGM_GRID, args.spot, args.r, args.q)
+    iv, success = generate_iv_surfaces(params64, T_GRID, LOGM_GRID, args.spot, args.r, args.q)
     surfaces_array = iv[success]
     if len(surfaces_array) == 0:
         print(" No valid surfaces generated!")

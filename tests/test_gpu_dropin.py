@@ -99,9 +99,42 @@ def test_cvae_state_dict_layout_and_hip_decode(mods, golden_dir):
     y = model.decode(z[:8], c[:8])
     assert y.requires_grad
     model.eval()
-    with pytest.raises(RuntimeError, match="CUDA"):
+    # the reference's default call: sample(n, c) with CPU conditioning returns CPU tensors; the
+    # decoder still runs on the model's GPU
+    with torch.no_grad():
+        s_cpu = model.sample(20, c[:1].cpu())
+        out_cpu = model.decode(z.cpu(), c.cpu())
+        out_gpu = model.decode(z, c)          # (the training-mode call above moved the BatchNorm statistics)
+    assert s_cpu.device.type == "cpu" and s_cpu.shape == (20, 5)
+    assert torch.equal(out_cpu, out_gpu.cpu())
+    # fused decode -> de-normalise -> exp / tanh, the path main() takes
+    model2, _ = _load_model(mods, golden_dir)
+    p32, p64 = model2.decode_parameters(z, c, torch.tensor(d["param_mean"]), torch.tensor(d["param_std"]))
+    from test_gpu_parity import assert_params_close
+    assert_params_close(p32.cpu().numpy(), g["params"])
+    assert torch.equal(p64, p32.double())
+    # a model on the CPU has no kernel to run on: loud error, no fallback
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         with torch.no_grad():
-            model.decode(z.cpu(), c.cpu())
+            model.cpu().decode(z.cpu(), c.cpu())
+    model.cuda()
+
+
+def test_cvae_without_dropout_modules_decodes_through_the_kernel(mods, golden_dir):
+    """dropout=0 drops the Dropout modules from the reference's Sequential (cvae_model.py:91,99), so
+    the decoder's state-dict indices become 0/3/6/9; the kernel path collects layers by type."""
+    torch.manual_seed(3)
+    model = mods["cvae_model"].ConditionalVAE_SingleHeston(dropout=0.0).cuda().eval()
+    assert "decoder.9.weight" in model.state_dict() and "decoder.12.weight" not in model.state_dict()
+    for m in model.decoder:
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    z, c = torch.randn(33, 4, device="cuda"), torch.randn(33, 8, device="cuda")
+    with torch.no_grad():
+        out = model.decode(z, c)
+        ref = model.decoder(torch.cat([z, c], dim=1))
+    assert torch.allclose(out, ref, atol=3e-5, rtol=3e-5)
 
 
 def test_cvae_arbitrage_penalty_and_loss(mods, golden_dir):

@@ -327,6 +327,45 @@ def test_surface_without_workspace_is_an_error(afiv, grid821):
         grid821.surface(dev(sample_params(2, 1)), SPOT, "A", keep_ratio=False)
 
 
+def test_flags_out_of_the_wrong_shape_is_rejected(afiv, grid821):
+    p = dev(sample_params(4, 1))
+    ratio = grid821.price(p)
+    short = torch.empty((3, 4), dtype=torch.int32, device="cuda")
+    flat = torch.empty((16,), dtype=torch.int32, device="cuda")
+    for bad in (short, flat):
+        with pytest.raises(ValueError, match="flags_out"):
+            grid821.implied_vol_checked(ratio, SPOT, "A", flags_out=bad)
+        with pytest.raises(ValueError, match="flags_out"):
+            grid821.surface(p, SPOT, "A", flags_out=bad)
+    with pytest.raises(TypeError):
+        grid821.surface(p, SPOT, "A", flags_out=torch.empty((4, 4), dtype=torch.int64, device="cuda"))
+
+
+@pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
+def test_two_streams_share_one_grid(afiv, variant):
+    """A grid object is immutable: implied-vol calls with different spots issued on two streams at
+    once (they overlap on the device: each takes milliseconds) give what each gives alone."""
+    logm = np.linspace(-0.2, 0.2, 50)
+    tau = np.round(np.linspace(30, 730, 20)) / 365.0
+    grid = afiv.Grid(logm, tau, R, Q)
+    ratio = grid.price(dev(sample_params(6000, 61)))
+    spots = (21000.0, 7000.0)
+    alone = [grid.implied_vol_checked(ratio, s, variant) for s in spots]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        both = []
+        for st, s in zip(streams, spots):
+            with torch.cuda.stream(st):
+                both.append(grid.implied_vol_checked(ratio, s, variant))
+        torch.cuda.synchronize()
+        for (iv, fl), (iv0, fl0) in zip(both, alone):
+            assert torch.equal(torch.nan_to_num(iv, nan=-1.0), torch.nan_to_num(iv0, nan=-1.0))
+            assert torch.equal(fl, fl0)
+    assert not torch.equal(torch.nan_to_num(alone[0][0], nan=-1.0), torch.nan_to_num(alone[1][0], nan=-1.0)) \
+        or variant != "B"
+
+
 def test_decode_matches_torch_golden(afiv, golden_dir):
     d = np.load(f"{golden_dir}/decoder.npz")
     g = np.load(f"{golden_dir}/golden_decode.npz")
