@@ -251,6 +251,35 @@ def test_regime_functions_match_reference_outputs(mods, golden_dir):
     assert ok == (not np.isnan(ref_iv).any())
     m = ~np.isnan(iv) & ~np.isnan(ref_iv)
     assert np.median(np.abs(iv[m] - ref_iv[m])) <= 1e-9
-    stats = R.regime_statistics(np.tile(p, (6, 1)) * (1 + 0.01 * np.arange(6))[:, None],
-                                g["tau"], g["logm"], spot, r, q)
-    assert stats is None or stats["mean_surface"].shape == (8, 21)
+
+
+def test_regime_statistics_reproduce_the_reference_loop_on_its_own_regime_parameters(mods, golden_dir):
+    """generate_regime_surfaces.py:296-362 on the first 64 parameter sets of each of the reference's
+    eight regimes (best_model_2025/regime_samples/all_regimes_heston_params.pt, read statically by
+    tests/golden/make_regime_fixture.py): valid surfaces, arbitrage-free count and the average
+    static / calendar violation counts equal those of the oracle's variant-B surfaces checked by the
+    reference's own check_all_arbitrage; the surface statistics equal NumPy's on the oracle's vols."""
+    R = mods["generate_regime_surfaces"]
+    g = np.load(f"{golden_dir}/regime_fixture.npz")
+    spot, r, q = float(g["spot"]), float(g["r"]), float(g["q"])
+    seen_partial = False
+    for name, p32, ref in zip(g["names"], g["params"], g["stats"]):
+        stats = R.regime_statistics(p32, g["T_grid"], g["logm_grid"], spot, r, q)
+        assert stats is not None, name
+        got = [stats["n_total"], stats["n_valid"], stats["arbitrage_free_count"],
+               stats["avg_static_violations"], stats["avg_calendar_violations"]]
+        assert got == list(ref), f"{name}: {got} != {list(ref)}"
+        assert stats["success_rate"] == ref[1] / ref[0] * 100
+        assert stats["arbitrage_free_pct"] == ref[2] / ref[1] * 100
+        seen_partial |= 0 < ref[1] < ref[0]
+        _ratio, iv_o, _ = oracle.surface_batch(p32.astype(np.float64), g["logm_grid"], g["T_grid"], spot, r, q, "B")
+        ok = ~np.isnan(iv_o).any(axis=(1, 2))
+        assert stats["surfaces"].shape == (int(ref[1]), 8, 21)
+        assert np.abs(stats["surfaces"] - iv_o[ok]).max() <= 1e-6
+        for key, fn in (("mean_surface", np.mean), ("std_surface", np.std), ("median_surface", np.median)):
+            assert np.abs(stats[key] - fn(iv_o[ok], axis=0)).max() <= 1e-6
+        assert np.abs(stats["atm_iv_mean"] - iv_o[ok][:, :, 10].mean(axis=0)).max() <= 1e-6
+        assert np.abs(stats["p95_surface"] - np.percentile(iv_o[ok], 95, axis=0)).max() <= 1e-6
+    assert seen_partial                                     # some regime loses surfaces to NaN points
+    assert R.regime_statistics(np.array([[2.0, 0.04, 0.3, -0.7, 0.04]]) * np.array([1, 1, 1, 1, -1.0]),
+                               g["T_grid"], g["logm_grid"], spot, r, q) is None      # no valid surface at all
