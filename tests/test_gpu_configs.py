@@ -184,16 +184,33 @@ def test_config4_stage1_loss_matrix(afiv, golden_dir):
     r, q = float(pin["r"]), float(pin["q"])
     days = pin["iv_surfaces"]                                   # all 500 days
     market = market_lattice(days, t_grid, logm_grid, r, q)
-    cand = sample_params(256, 4)
+    n_cand = 4096                                               # the configured size
+    cand = sample_params(n_cand, 4)
     cand[:6] = pin["params"][:6]                                # some calibrated sets: small losses
     grid = afiv.Grid(logm_grid, t_grid, r, q)
     model = grid.price(dev(cand))
     loss = grid.stage1_objective(model, dev(cand), dev(market), float(pin["drift_weight"])).cpu().numpy()
-    assert loss.shape == (256, 500)
+    assert loss.shape == (n_cand, 500)
     model_h = model.cpu().numpy()
+    # the whole 4096 x 500 matrix against NumPy (objective_stage1 vectorised over candidates)
+    flat_model = model_h.reshape(n_cand, -1)
+    atm = np.abs(np.tile(logm_grid, len(t_grid))) < 0.05
+    feller = 5.0 * np.maximum(0.0, cand[:, 2] ** 2 - 2 * cand[:, 0] * cand[:, 1])
+    for d in range(500):
+        y = market[d].ravel()
+        mask = ~np.isnan(y)
+        m = flat_model[:, mask]
+        ref = np.sqrt(np.mean((m - y[mask]) ** 2, axis=1)) \
+            + float(pin["drift_weight"]) * np.abs(m[:, atm[mask]].mean(axis=1) - y[mask & atm].mean()) + feller
+        ref = np.where(np.isnan(m).any(axis=1) | (m < 0).any(axis=1), 1e10, ref)
+        assert np.all(np.abs(loss[:, d] - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))), d
+    assert (loss >= 1e10).any() and (loss < 1.0).any()
+    # ragged shapes: neither a multiple of the kernel's candidate tile nor of its day tile
+    sub = grid.stage1_objective(model[:37].contiguous(), dev(cand[:37]), dev(market[:70]), float(pin["drift_weight"]))
+    assert np.array_equal(sub.cpu().numpy(), loss[:37, :70])
     rng = np.random.default_rng(4)
     checked = 0
-    for c in list(range(6)) + list(rng.choice(256, 10, replace=False)):
+    for c in list(range(6)) + list(rng.choice(n_cand, 10, replace=False)):
         for d in rng.choice(500, 12, replace=False):
             mask = ~np.isnan(market[d])
             ref = oracle.stage1_objective(cand[c], days[d], t_grid, logm_grid, r, q, float(pin["drift_weight"]),
