@@ -33,7 +33,7 @@
 namespace {
 using namespace afivbs;
 
-constexpr int FAST_THREADS = 256;
+constexpr int FAST_THREADS = 512;
 constexpr int FAST_WAVES = FAST_THREADS / 64;
 constexpr int BACH_ROW = 8;                       // 5 coefficients padded to 32-byte rows
 constexpr int BACH_ROWS = AFIV_BACH_NSEG_A + AFIV_BACH_NSEG_B;
@@ -100,7 +100,7 @@ __device__ __forceinline__ double rcp_step(double x)
 }
 
 template <bool CHECKS>
-__global__ __launch_bounds__(FAST_THREADS) void iv_fast_kernel(GridView g, const double *__restrict__ ratio,
+__global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void iv_fast_kernel(GridView g, const double *__restrict__ ratio,
                                                                int64_t N, double spot, double *__restrict__ iv_out,
                                                                int32_t *__restrict__ flags)
 {
