@@ -112,9 +112,12 @@ __global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     d2v *ends = reinterpret_cast<d2v *>(strike + AFIV_MAX_STRIKES);            // [per] objective at 0.001 and 3.0
     d2v *fk = ends + per;                                                      // [per] log(F/K), F/K
     float *bach = reinterpret_cast<float *>(fk + per);                         // [BACH_ROWS][BACH_ROW]
+    // per wave and maturity: negative-butterfly count, and whether the row holds a NaN / negative ratio
+    __shared__ int fly_all[FAST_WAVES][AFIV_MAX_MATURITIES];
     __shared__ int skip_all[FAST_WAVES][AFIV_MAX_MATURITIES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *skip_t = skip_all[wave];
+    int *fly_t = fly_all[wave];
 
     load_erfcx_table(tab);
     for (int i = tid; i < BACH_ROWS * BACH_ROW; i += FAST_THREADS) {
@@ -163,20 +166,17 @@ __global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const double *src = ratio + s * per;
         double *dst = iv_out + s * per;
         if (CHECKS) {
-            // maturities whose ratios hold a NaN or a negative value take no part in the butterfly rule
+            // Maturities whose ratios hold a NaN or a negative value take no part in the butterfly
+            // rule, which is only known once the whole row has been seen: negative butterflies are
+            // counted per maturity (both events are rare, so the LDS traffic is too) and the rows
+            // are sorted out after the surface's last point.  Each ratio is read from memory once.
             __builtin_amdgcn_wave_barrier();
             skip_t[lane] = 0;
+            fly_t[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < per; i += 64) {
-                const double y = src[i];
-                if (isnan(y) || y < 0) skip_t[small_div(i, inv_nK)] = 1;       // benign race: all writers store 1
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        int n_nan = 0, n_bad = 0, n_fly = 0, n_stat = 0, n_cal = 0;
+        int n_nan = 0, n_bad = 0, n_stat = 0, n_cal = 0;
         double p_prev = nan;                                 // re-priced values of the previous 64 points
         for (int b = 0; b < nbatch; ++b) {
             const int i = (b << 6) + lane;
@@ -262,9 +262,10 @@ __global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 const double below = lane >= nK ? c_cur : c_prev;
                 if (live && k >= 1 && left < p_cur - 1e-6) n_stat++;
                 if (live && t >= 1 && below > p_cur + 1e-6) n_cal++;
-                if (live && k + 2 < nK && !skip_t[t]) {
-                    const double bf = y - 2 * src[i + 1] + src[i + 2];
-                    if (bf < 0) n_fly++;
+                if (live && (isnan(y) || y < 0)) skip_t[t] = 1;         // benign race: all writers store 1
+                if (live && k + 2 < nK) {
+                    const double bf = y - 2 * src[i + 1] + src[i + 2];  // the same cache lines as y
+                    if (bf < 0) atomicAdd(&fly_t[t], 1);
                 }
                 p_prev = p_cur;
             }
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         if (CHECKS) {
             n_nan = wave_sum(n_nan);
             n_bad = wave_sum(n_bad);
-            n_fly = wave_sum(n_fly);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int n_fly = wave_sum(lane < nT && !skip_t[lane] ? fly_t[lane] : 0);
             n_stat = wave_sum(n_stat);
             n_cal = wave_sum(n_cal);
             if (lane == 0) {
