@@ -99,8 +99,14 @@ int afiv_price(const afiv_grid *g, const double *params, int64_t N, double *rati
 
 /* ---- implied volatility: replaces the inner loop body of generate_iv_surface
  * (generate_iv_surface_by_date.py:296-318 for AFIV_VARIANT_A, generate_regime_surfaces.py:138-177
- * for AFIV_VARIANT_B): guard, then Brent's method on [0.001, 3.0] with xtol 1e-6 as
- * scipy.optimize.brentq runs it; NaN where the reference yields NaN.
+ * for AFIV_VARIANT_B): the reference's guard, then the root of the Black-Scholes objective on
+ * [0.001, 3.0] under scipy.optimize.brentq's rules -- f(0.001) == 0 returns 0.001, equal signs at
+ * the two ends or a NaN objective give NaN -- so NaN where the reference yields NaN.  Inside a
+ * valid bracket AFIV_VARIANT_B and AFIV_VARIANT_A_BRENT make brentq's decisions one for one
+ * (xtol 1e-6, rtol 4 eps, 100 iterations; the arithmetic of a step differs from brentq.c's in the
+ * last bits: one quotient for the inverse-quadratic step, fused multiply-adds in the tolerance),
+ * which lands on brentq's own root to 1e-10 on 99.9 % of points; AFIV_VARIANT_A converges to the
+ * root itself and is within 5e-7 of brentq's answer wherever the vega is above 1e-3 of the spot.
  * ratio: device [N,nT,nK]; iv_out: device [N,nT,nK]. */
 int afiv_implied_vol(const afiv_grid *g, const double *ratio, int64_t N, double spot,
                      int variant, double *iv_out, void *stream);
@@ -123,9 +129,12 @@ int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, in
                    double spot, int bs_form, int32_t *flags_out, uint8_t *mask_out, void *stream);
 
 /* ---- implied vol and checks in one pass over the lattice: afiv_implied_vol followed by
- * afiv_arb_check(bs_form = variant, no mask) with identical results, but each vol's re-priced
- * Black-Scholes value is taken from the root finder's last objective evaluation instead of being
- * recomputed.  Replaces the body of generate_iv_surface plus check_all_arbitrage
+ * afiv_arb_check(bs_form = variant, no mask), but each vol's re-priced Black-Scholes value is
+ * taken from the root finder's last objective evaluation instead of being recomputed.  The vols
+ * are identical to afiv_implied_vol's; the flag words are identical to the two-call sequence's
+ * except where a price difference sits within rounding (1e-11) of its 1e-6 threshold: the two
+ * evaluate the same formula with different roundings (one shared exponential and a reciprocal-based
+ * quotient here, separate exponentials and an IEEE quotient there).  Replaces the body of generate_iv_surface plus check_all_arbitrage
  * (generate_regime_surfaces.py:320-335 calls them back to back). */
 int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N, double spot,
                              int variant, double *iv_out, int32_t *flags_out, void *stream);
