@@ -405,6 +405,9 @@ def main():
                                        ", no collective")},
             "roofline": dominant,
             "roofline_other_kernel": other,
+            # the same step without anything but rank 0's two kernels (events on the launch stream): what
+            # `value` would be if the exchange were free
+            "kernels_only": {"ms_per_step": (k_price + k_iv) * 1e3, "value": total / (k_price + k_iv)},
             "whole_path_tflops": surface_flops(N_MATURITIES, N_STRIKES) * value / 1e12,
             "check": {"valid_surfaces_frac": float(np.mean((fl[:, 3] & 4) != 0)),
                       "arbitrage_free_frac": float(np.mean((fl[:, 3] & 1) != 0)),
