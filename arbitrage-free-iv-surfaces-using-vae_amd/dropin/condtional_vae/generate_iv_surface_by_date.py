@@ -56,7 +56,7 @@ def generate_iv_surfaces(params, T_grid, logm_grid, spot, r, q, variant="A", ret
     iv, flags, _ratio = grid.surface(p, float(spot), variant)
     iv_np = iv.cpu().numpy()
     flags_np = flags.cpu().numpy()
-    bit = _afiv.STATUS_SUCCESS_A if variant in ("A", 0) else _afiv.STATUS_SUCCESS_B
+    bit = _afiv.STATUS_SUCCESS_A if variant in ("A", 0, "A_BRENT", 2) else _afiv.STATUS_SUCCESS_B
     success = (flags_np[:, 3] & bit) != 0
     if return_flags:
         return iv_np, success, flags_np
