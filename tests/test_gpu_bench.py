@@ -33,3 +33,21 @@ def test_two_self_launched_ranks_reproduce_the_single_rank_flags(tmp_path):
     for line in (one, two):
         assert line["roofline"]["kernel"] in ("price_kernel", "iv_fast_kernel") and line["roofline"]["frac"] > 0
         assert "REDUCED" in line["config"]["workload"]          # not the configured batch: says so
+
+
+def test_launch_under_torch_distributed_run(tmp_path):
+    """The other way in: one rank per process started by torch.distributed.run, rank and world
+    size taken from the environment (two ranks on the one GPU, gloo)."""
+    dump = str(tmp_path / "tdr.npy")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--surfaces", "2048", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--dump", dump]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["surfaces_per_gpu_per_step"] == 1024
+    assert "final_gather" in line and line["kernels_only"]["value"] > 0
+    assert np.load(dump).shape == (2048, 4)
