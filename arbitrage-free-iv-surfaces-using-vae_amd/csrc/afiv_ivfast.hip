@@ -16,8 +16,8 @@
 //      median and below 1e-4 for total vols under 1;
 //   2. third-order Householder steps on the objective itself (its derivatives are closed forms of
 //      d1, d2 and the exponential the evaluation has computed anyway), each candidate kept inside
-//      the bracket (bisection otherwise), until the Newton step is below 1e-8 or the objective is
-//      zero to the rounding of its own terms.
+//      the bracket (bisection otherwise), until the Newton step is below 1e-8, the objective is
+//      zero to the rounding of its own terms, or the bracket is narrower than brentq's xtol.
 // Two evaluations per point on the benchmark lattice (one where the guess is already within 1e-8)
 // instead of Brent's ten, the same for every lane: a wave solves 64 consecutive lattice points in
 // lockstep, reads and writes them coalesced, and compares neighbours (strike k-1, maturity t-1)
@@ -99,10 +99,12 @@ __device__ __forceinline__ double rcp_step(double x)
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 }
 
+// Four waves per SIMD (128 VGPRs; the compiler's own choice is 130 and three waves), two workgroups
+// per CU: the lattice's tables are shared by eight surfaces in flight.
 template <bool CHECKS>
-__global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void iv_fast_kernel(GridView g, const double *__restrict__ ratio,
-                                                               int64_t N, double spot, double *__restrict__ iv_out,
-                                                               int32_t *__restrict__ flags)
+__global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, double spot,
+                    double *__restrict__ iv_out, int32_t *__restrict__ flags)
 {
     extern __shared__ double dyn[];
     const int nT = g.nT, nK = g.nK, per = nT * nK;
