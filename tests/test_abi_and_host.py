@@ -23,7 +23,8 @@ def test_header_declares_the_expected_entry_points():
     for s in ("afiv_version", "afiv_grid_create", "afiv_grid_destroy", "afiv_grid_traits", "afiv_price",
               "afiv_implied_vol", "afiv_arb_check", "afiv_implied_vol_checked", "afiv_surface", "afiv_decoder_create",
               "afiv_decoder_destroy", "afiv_decode", "afiv_arbitrage_penalty",
-              "afiv_stage1_objective", "afiv_error_string", "afiv_debug_math"):
+              "afiv_stage1_objective", "afiv_error_string", "afiv_debug_math", "afiv_surface_static",
+              "afiv_density_wasserstein", "afiv_ensemble_stats"):
         assert s in syms
 
 
@@ -50,6 +51,8 @@ def test_error_strings_and_null_checks_without_gpu(afiv):
     assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 65, x.ctypes.data_as(dp), 4, 0.0, 0.0, 1, 0) == -2
     assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 4, x.ctypes.data_as(dp), 65, 0.0, 0.0, 1, 0) == -2
     assert lib.afiv_price(None, None, 1, None, None) == -1
+    assert lib.afiv_surface_static(None, None, 1, 1.0, 0, None, None, None) == -1
+    assert b"scratch" in lib.afiv_error_string(-6)
     assert lib.afiv_decode(None, None, None, 1, 1, None, None, None, None) == -1
     assert lib.afiv_decoder_create(None, None) == -1
     assert lib.afiv_grid_destroy(None) == 0
