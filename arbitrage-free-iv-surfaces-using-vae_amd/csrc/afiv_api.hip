@@ -206,14 +206,22 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
             if (t == 1 || d > hi) hi = d;
         }
         if (ok && hi - lo <= 3) {
+            // base step + k extra days, k = 0..3.  When only two step lengths occur and the longer one
+            // is the more frequent (round(linspace(...)) days: mostly 37, some 36), take the longer as
+            // the base and MINUS one day as the extra: fewer extra factors to multiply in.
+            long n_lo = 0;
+            for (int t = 1; t < nT; ++t)
+                if ((long)(tau[t] * 365.0) - (long)(tau[t - 1] * 365.0) == lo) ++n_lo;
+            const bool down = hi - lo == 1 && n_lo < (nT - 1) - n_lo;
+            const long base = down ? hi : lo;
             unsigned long long sel = 0;
             for (int t = 1; t < nT; ++t) {
                 const long d = (long)(tau[t] * 365.0) - (long)(tau[t - 1] * 365.0);
-                sel |= (unsigned long long)(d - lo) << (2 * t);
+                sel |= (unsigned long long)(down ? base - d : d - base) << (2 * t);
             }
             v.step_count = hi == lo ? 1 : 2;
-            v.step_dt[0] = (double)lo / 365.0;
-            v.step_dt[1] = 1.0 / 365.0;
+            v.step_dt[0] = (double)base / 365.0;
+            v.step_dt[1] = (down ? -1.0 : 1.0) / 365.0;
             v.step_sel = sel;
         }
     }

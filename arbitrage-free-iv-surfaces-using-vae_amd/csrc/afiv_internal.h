@@ -31,8 +31,8 @@ struct GridView {
     int sym, nH, nHpad;
     const double *tab_sym;
     // Regular term structures (afiv_price.hip, NFAC): step_count = 0 (none), 1 (successive year
-    // fractions are step_dt[0] apart) or 2 (step_dt[0] plus k times step_dt[1] = one day, k <= 3 in
-    // bits 2t, 2t+1 of step_sel for the step from maturity t-1 to t).
+    // fractions are step_dt[0] apart) or 2 (step_dt[0] plus k times step_dt[1] = plus or minus one
+    // day, k <= 3 in bits 2t, 2t+1 of step_sel for the step from maturity t-1 to t).
     int step_count;
     double step_dt[2];
     unsigned long long step_sel;

@@ -483,6 +483,7 @@ def test_price_against_60_digit_quadrature_at_the_corners_and_on_the_series_bran
     ([30, 60, 90, 120, 150, 180], 1),                      # one increment: one step factor
     ([30, 67, 104, 141, 177, 214, 250, 288, 325], 2),      # 36..38 days: base step plus one-day factors
     ([10, 13, 16, 20, 23, 26, 29, 33], 2),                 # base 3 days, up to 1 extra
+    ([30, 67, 104, 140, 177, 214, 251, 287, 324], 2),      # mostly 37 days, some 36: base 37 minus one-day factors
     ([30, 60, 91, 182, 273, 365, 547, 730], 0),            # irregular: every maturity evaluated directly
 ])
 def test_price_regular_and_irregular_term_structures(afiv, days, stepped):
