@@ -22,8 +22,9 @@ namespace {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Device address of `scratch` on each GPU, resolved at the first afiv_surface_static call made with
-// that GPU current.  Racing first calls resolve the same address twice and store the same value.
+// Device address of `scratch` on each GPU, resolved when the first grid is created on that GPU (and
+// again on demand by afiv_surface_static, should the table be empty).  Racing first calls resolve
+// the same address twice and store the same value.
 constexpr int MAX_DEVICES = 64;
 std::atomic<double *> scratch_addr[MAX_DEVICES];
 
@@ -62,7 +63,7 @@ const char *afiv_error_string(int code)
         case AFIV_OK: return "ok";
         case AFIV_E_NULL: return "required pointer is NULL";
         case AFIV_E_SHAPE: return "size out of supported range";
-        case AFIV_E_HIP: return "HIP runtime call or kernel launch failed";
+        case AFIV_E_HIP: return "HIP runtime call, kernel launch or host allocation failed";
         case AFIV_E_ARG: return "bad argument (enum value, or object used on a different device)";
         case AFIV_E_WORKSPACE: return "grid was created without the workspace this call needs";
         case AFIV_E_SCRATCH: return "batch exceeds the static scratch of afiv_surface_static "
@@ -73,7 +74,7 @@ const char *afiv_error_string(int code)
 
 int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *tau, int nT, double r,
                      double q, int trunc_days, int64_t workspace_surfaces)
-{
+try {
     if (!out || !logm || !tau) return AFIV_E_NULL;
     *out = nullptr;
     if (nK < 1 || nK > AFIV_MAX_STRIKES || nT < 1 || nT > AFIV_MAX_MATURITIES) return AFIV_E_SHAPE;
@@ -167,6 +168,13 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     afiv_grid *g = new (std::nothrow) afiv_grid();
     if (!g) return AFIV_E_HIP;
     if (hipGetDevice(&g->device) != hipSuccess) { delete g; return AFIV_E_HIP; }
+    {
+        // Resolve this device's static scratch here, at set-up: afiv_surface_static needs a grid of
+        // the current device, so its own look-up then never runs first inside a stream capture.
+        double *unused = nullptr;
+        const int rc = scratch_for_current_device(&unused);
+        if (rc) { delete g; return rc; }
+    }
     double *dev = nullptr;
     if (hipMalloc((void **)&dev, nd * sizeof(double)) != hipSuccess) { delete g; return AFIV_E_HIP; }
     if (hipMemcpy(dev, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
@@ -238,6 +246,8 @@ int afiv_grid_create(afiv_grid **out, const double *logm, int nK, const double *
     }
     *out = g;
     return AFIV_OK;
+} catch (...) {
+    return AFIV_E_HIP;   // host allocation of the staging tables failed; no device memory is held yet
 }
 
 int afiv_grid_destroy(afiv_grid *g)
@@ -349,7 +359,7 @@ int afiv_surface_static(const afiv_grid *g, const double *params, int64_t N, dou
 }
 
 int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w)
-{
+try {
     if (!out || !w) return AFIV_E_NULL;
     *out = nullptr;
     static const int IN[4] = {12, 32, 64, 128}, OUT[4] = {32, 64, 128, 5};
@@ -393,6 +403,8 @@ int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w)
     d->v.pstd = dev + npacked + 5;
     *out = d;
     return AFIV_OK;
+} catch (...) {
+    return AFIV_E_HIP;   // host allocation of the packed weights failed; no device memory is held yet
 }
 
 int afiv_decoder_destroy(afiv_decoder *d)

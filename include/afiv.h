@@ -36,7 +36,7 @@ enum {
     AFIV_OK = 0,
     AFIV_E_NULL = -1,        /* required pointer is NULL */
     AFIV_E_SHAPE = -2,       /* a size is out of the supported range */
-    AFIV_E_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+    AFIV_E_HIP = -3,         /* a HIP runtime call, kernel launch or host allocation failed */
     AFIV_E_ARG = -4,         /* bad enum / flag value */
     AFIV_E_WORKSPACE = -5,   /* the call needs a workspace the grid was created without */
     AFIV_E_SCRATCH = -6      /* the batch exceeds the static scratch of afiv_surface_static */
@@ -156,7 +156,9 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
  * 8 x 21), else AFIV_E_SCRATCH; larger batches are the caller's to split.  Every call on a GPU
  * shares that GPU's array (each GPU holds its own copy until the process ends): calls that overlap
  * on one GPU -- different streams or threads -- race on it, so issue them in one stream's order.
- * Nothing in the array has to be cleared between calls. */
+ * Nothing in the array has to be cleared between calls.  The array's device address is looked up
+ * when a grid is created (afiv_grid_create, with that GPU current), so a first call
+ * issued inside a stream capture finds it resolved. */
 int afiv_surface_static(const afiv_grid *g, const double *params, int64_t N, double spot, int variant,
                         double *iv_out, int32_t *flags_out, void *stream);
 
