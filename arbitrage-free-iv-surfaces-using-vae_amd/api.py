@@ -32,13 +32,16 @@ def _ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _need(t: torch.Tensor, dtype, what: str, device: torch.device) -> torch.Tensor:
+def _need(t: torch.Tensor, dtype, what: str, device: torch.device, output: bool = False) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{what} must be a torch.Tensor")
     if t.device != device:
         raise ValueError(f"{what} is on {t.device}, the grid/decoder lives on {device}")
     if t.dtype != dtype:
         raise TypeError(f"{what} must be {dtype}, got {t.dtype}")
+    if output and not t.is_contiguous():
+        # a contiguous copy would receive the results and be dropped
+        raise ValueError(f"{what} must be contiguous: the kernels write into it in place")
     return t.contiguous()
 
 
@@ -95,13 +98,13 @@ class Grid:
         return p
 
     def _lattice(self, t: torch.Tensor, what: str) -> torch.Tensor:
-        t = _need(t, torch.float64, what, self.device)
+        t = _need(t, torch.float64, what, self.device, output=what.endswith("out"))
         if t.dim() != 3 or t.shape[1] != self.nT or t.shape[2] != self.nK:
             raise ValueError(f"{what} must be [N,{self.nT},{self.nK}], got {tuple(t.shape)}")
         return t
 
     def _flags(self, t: torch.Tensor, n: int) -> torch.Tensor:
-        t = _need(t, torch.int32, "flags_out", self.device)
+        t = _need(t, torch.int32, "flags_out", self.device, output=True)
         if tuple(t.shape) != (n, 4):
             raise ValueError(f"flags_out must be [{n},4], got {tuple(t.shape)}")
         return t

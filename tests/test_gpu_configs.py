@@ -229,6 +229,50 @@ def test_config4_stage1_loss_matrix(afiv, golden_dir):
     assert viol.any() and (~viol).any()
 
 
+@pytest.mark.parametrize("nT,nK,n_cand,n_days", [(1, 12, 5, 3), (3, 5, 33, 65), (20, 50, 70, 130), (64, 64, 9, 64),
+                                                 (8, 21, 1, 1), (2, 64, 32, 128)])
+def test_stage1_loss_matrix_on_other_lattices(afiv, nT, nK, n_cand, n_days):
+    """The loss-matrix kernel walks the lattice in 128-point chunks and tiles 64 days x 32 candidates:
+    lattices shorter and longer than a chunk, tile remainders in both directions, market rows with
+    holes (dropped points, :185), days left with fewer than ten points (NaN: the reference skips
+    them, :202-203), model rows holding a NaN or a negative ratio (1e10, :270-271) -- against the
+    same formula in NumPy.  The model ratios are synthetic: only the objective is under test."""
+    rng = np.random.default_rng(1000 * nT + nK)
+    logm = np.sort(rng.uniform(-0.3, 0.3, nK))
+    logm[nK // 2] = 0.01                                         # at least one near-the-money strike
+    tau = np.sort(rng.uniform(0.05, 2.0, nT))
+    per = nT * nK
+    model = rng.uniform(0.0, 1.0, (n_cand, nT, nK))
+    market = rng.uniform(0.0, 1.0, (n_days, nT, nK))
+    market[rng.uniform(size=market.shape) < 0.15] = np.nan       # holes
+    if n_days > 2:
+        market[1] = np.nan                                       # an empty day
+        market[2].reshape(-1)[min(9, per):] = np.nan             # at most nine points
+    if n_cand > 4:
+        model[1, 0, 0] = np.nan
+        model[3, -1, -1] = -1e-3
+    cand = sample_params(n_cand, 7)
+    grid = afiv.Grid(logm, tau, R, Q)
+    w = 0.75
+    loss = grid.stage1_objective(dev(model), dev(cand), dev(market), w).cpu().numpy()
+    assert loss.shape == (n_cand, n_days)
+    atm = np.abs(np.tile(logm, nT)) < 0.05
+    feller = 5.0 * np.maximum(0.0, cand[:, 2] ** 2 - 2 * cand[:, 0] * cand[:, 1])
+    flat = model.reshape(n_cand, -1)
+    for d in range(n_days):
+        y = market[d].ravel()
+        mask = ~np.isnan(y)
+        if mask.sum() < 10:
+            assert np.isnan(loss[:, d]).all(), d
+            continue
+        m = flat[:, mask]
+        with np.errstate(invalid="ignore"):
+            drift = np.abs(m[:, atm[mask]].mean(axis=1) - y[mask & atm].mean()) if (mask & atm).any() else 0.0
+            ref = np.sqrt(np.mean((m - y[mask]) ** 2, axis=1)) + w * drift + feller
+        ref = np.where(np.isnan(m).any(axis=1) | (m < 0).any(axis=1), 1e10, ref)
+        assert np.all(np.abs(loss[:, d] - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))), d
+
+
 STRESS_RHO = (-0.999, -0.99, -0.95, 0.95, 0.999)
 STRESS_SIGMA = (1e-5, 1e-4, 1e-3, 1.0, 3.0, 5.0)
 STRESS_KAPPA = (0.01, 2.0, 20.0)
@@ -339,6 +383,62 @@ def test_config4_stage2_density_wasserstein(afiv, golden_dir):
             fin = dist[c, d][np.isfinite(dist[c, d])]
             want = 1e10 if base_h[c, d] >= 1e10 else base_h[c, d] + float(pin["wasserstein_weight"]) * (fin.mean() if fin.size else 0.0)
             assert abs(total[c, d] - want) <= 1e-12 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("nT,nK,n_cand,n_days", [(1, 3, 2, 2), (5, 7, 65, 3), (64, 64, 3, 5), (2, 50, 300, 2)])
+def test_density_wasserstein_on_other_lattices(afiv, nT, nK, n_cand, n_days):
+    """The density term on lattices other than the calibration's 8 x 50: the shortest strike grid a
+    second difference exists on, the largest lattice, more candidates than one launch's workgroups
+    take in one pass -- synthetic price rows (convex in the strike plus noise, so that some second
+    differences are clipped), rows that make the reference return inf (a NaN or negative model
+    ratio, a density that sums to nothing) and absent maturities (NaN market row) -- against
+    scipy.stats.wasserstein_distance on the reference's own densities (:121-147)."""
+    from scipy.stats import wasserstein_distance
+    rng = np.random.default_rng(100 * nT + nK)
+    fine = np.linspace(-0.25, 0.2, nK)
+    tau = np.sort(rng.uniform(0.05, 2.0, nT))
+    r = 0.05
+
+    def rows(n):
+        a = rng.uniform(0.5, 3.0, (n, nT, 1))
+        base = np.maximum(1.0 - np.exp(fine)[None, None, :], 0.0) + 0.05 * np.exp(-a * (fine[None, None, :] ** 2) * 40)
+        return base + 2e-4 * rng.standard_normal((n, nT, nK))
+
+    model, market = np.abs(rows(n_cand)), np.abs(rows(n_days))
+    model[0, 0, nK // 2] = np.nan                                 # -> inf
+    model[-1, -1, 0] = -1e-9                                      # -> inf
+    market[0, -1] = np.nan                                        # absent maturity -> NaN
+    if n_days > 1:
+        market[1, 0] = np.linspace(1.0, 0.5, nK)                  # a straight line: no density -> inf
+    grid = afiv.Grid(fine, tau, r, 0.0)
+    dist = grid.density_wasserstein(dev(model), dev(market)).cpu().numpy()
+    assert dist.shape == (n_cand, n_days, nT)
+    dlm = fine[1] - fine[0]
+
+    def density(v, t):
+        d = np.zeros(nK)
+        for i in range(1, nK - 1):
+            d[i] = np.exp(r * tau[t]) * ((v[i + 1] - 2 * v[i] + v[i - 1]) / dlm ** 2)
+        return np.maximum(d, 0)
+
+    n_fin = n_inf = 0
+    for c in list(range(min(n_cand, 6))) + [n_cand - 1]:
+        for d in range(n_days):
+            for t in range(nT):
+                got = dist[c, d, t]
+                if np.isnan(market[d, t]).any():
+                    assert np.isnan(got)
+                    continue
+                mdl = model[c, t]
+                md, dd = density(market[d, t], t), density(mdl, t)
+                if np.isnan(mdl).any() or (mdl < 0).any() or md.sum() < 1e-10 or dd.sum() < 1e-10:
+                    assert np.isinf(got), (c, d, t, got)
+                    n_inf += 1
+                    continue
+                ref = wasserstein_distance(fine, fine, md / md.sum(), dd / dd.sum())
+                assert abs(got - ref) <= 1e-12 * max(1.0, abs(ref)) + 1e-15, (c, d, t, got, ref)
+                n_fin += 1
+    assert n_inf >= 2 and (n_fin > 0 or nK == 3)
 
 
 def test_config3_full_size_one_million_surfaces(afiv):

@@ -339,6 +339,18 @@ def test_flags_out_of_the_wrong_shape_is_rejected(afiv, grid821):
             grid821.surface(p, SPOT, "A", flags_out=bad)
     with pytest.raises(TypeError):
         grid821.surface(p, SPOT, "A", flags_out=torch.empty((4, 4), dtype=torch.int64, device="cuda"))
+    # outputs are written in place: a strided view must be refused, not silently copied
+    wide = torch.empty((4, 8, 42), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError, match="contiguous"):
+        grid821.price(p, out=wide[:, :, ::2])
+    with pytest.raises(ValueError, match="contiguous"):
+        grid821.surface(p, SPOT, "A", iv_out=wide[:, :, ::2])
+    with pytest.raises(ValueError, match="contiguous"):
+        grid821.implied_vol_checked(ratio, SPOT, "A", flags_out=torch.empty((4, 8), dtype=torch.int32,
+                                                                             device="cuda")[:, ::2])
+    # strided INPUTS are fine (copied)
+    got = grid821.implied_vol(torch.stack([ratio, ratio], dim=-1)[..., 0], SPOT, "A")
+    assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(grid821.implied_vol(ratio, SPOT, "A")))
 
 
 @pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
