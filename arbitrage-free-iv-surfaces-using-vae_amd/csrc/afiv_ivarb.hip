@@ -5,10 +5,11 @@
 // identical inputs (mul and add are never fused here).
 //
 //   implied vol : generate_iv_surface_by_date.py:296-318 (variant A) and
-//                 generate_regime_surfaces.py:138-177 (variant B); the root finder follows
-//                 scipy.optimize.brentq step for step (one grid point per lane at a time), because
-//                 variant B's objective is not monotone and only the same iteration path
-//                 lands on the same root.
+//                 generate_regime_surfaces.py:138-177 (variant B); the root finder makes
+//                 scipy.optimize.brentq's decisions one for one (one grid point per lane at a time;
+//                 a step's arithmetic differs from brentq.c's in the last bits), because variant
+//                 B's objective is not monotone and only the same iteration path lands on the
+//                 same root.
 //   checks      : generate_regime_surfaces.py:188-283 and cvae_model.py:272-285.
 #include "afiv_bs.h"
 

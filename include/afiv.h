@@ -53,7 +53,7 @@ enum {
 enum {
     AFIV_VARIANT_A = 0,        /* forward form, generate_iv_surface_by_date.py:308-312 */
     AFIV_VARIANT_B = 1,        /* spot form as written in generate_regime_surfaces.py:154-159 */
-    AFIV_VARIANT_A_BRENT = 2   /* forward form, brentq's iteration path step for step */
+    AFIV_VARIANT_A_BRENT = 2   /* forward form on brentq's iteration path (same decisions up to last-bit rounding) */
 };
 
 /* Limits of this build. */
