@@ -157,7 +157,7 @@ def test_cvae_arbitrage_penalty_and_loss(mods, golden_dir):
     recon, mu, logvar = model(x, c)
     total, rl, kl, fl, al = model.loss_function(recon, x, mu, logvar, mean, std)
     manual = rl + model.beta * kl + model.feller_penalty_weight * fl + model.arbitrage_penalty_weight * al
-    assert abs(float(total) - float(manual)) < 1e-4
+    assert abs(float(total.detach()) - float(manual.detach())) < 1e-4
     total.backward()
 
 
