@@ -373,6 +373,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                     }
                     x0 = cf_eval(st0, m, phi, wp, T, ddt, Dq, ex0, sct);
                 }
+                // The previous step's epilogue read its partial tiles from this buffer: every wave
+                // must be past it before the first operand of this step is stored.  Placed here, one
+                // evaluation into the step, the barrier finds the waves already through.
+                if (tl == 0) __syncthreads();
                 if (sl < SPB) {   // spare lanes of the last wave own no row
                     if (SYM) {
                         xw[(sl * MT + tl) * XSTRIDE + 0 * NQ + n] = x0.x;
@@ -473,7 +477,6 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                 }
             }
         }
-        __syncthreads();          // partial tiles consumed before step G+1 overwrites this buffer
         prev_chunk = chunk;
         prev_tile = tile;
         if (++tile == ntiles) {
