@@ -17,6 +17,7 @@ __global__ __launch_bounds__(1024) void k(double *out, unsigned long long *ticks
     v4d acc = {0, 0, 0, 0};
     __syncthreads();
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+#pragma unroll 8
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {
 #pragma unroll
