@@ -62,24 +62,30 @@ def test_static_scratch_entry_point_limits(afiv):
     assert rc == 0
 
 
-def test_static_scratch_entry_point_under_graph_capture(afiv):
+@pytest.mark.parametrize("nT,nK,variant", [(8, 21, "A"), (64, 64, "A"), (64, 64, "B"), (20, 50, "A_BRENT")])
+def test_static_scratch_entry_point_under_graph_capture(afiv, nT, nK, variant):
     """What the entry point is for: a whole price -> implied vol -> checks pass captured into a HIP
-    graph (capture forbids allocation) and replayed on new parameters in the same buffers."""
-    logm = np.linspace(-0.2, 0.2, 21)
-    tau = np.array([0.08333333, 0.16666667, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+    graph (capture forbids allocation) and replayed on new parameters in the same buffers.  The
+    largest lattice makes the kernels ask for more than the default dynamic LDS, which is a function
+    attribute set at launch time -- legal under capture, unlike an allocation."""
+    if (nT, nK) == (8, 21):
+        logm = np.linspace(-0.2, 0.2, 21)
+        tau = np.array([0.08333333, 0.16666667, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+    else:
+        logm = np.linspace(-0.3, 0.25, nK)
+        tau = np.round(np.linspace(20, 900, nT)) / 365.0
     grid = afiv.Grid(logm, tau, R, Q)
     n = 500
     p = _params(n, 11).clone()
-    iv = torch.empty((n, 8, 21), dtype=torch.float64, device="cuda")
+    iv = torch.empty((n, nT, nK), dtype=torch.float64, device="cuda")
     fl = torch.empty((n, 4), dtype=torch.int32, device="cuda")
-    grid.surface_static(p, SPOT, "A", iv_out=iv, flags_out=fl)        # warm-up: resolves the array's address
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        grid.surface_static(p, SPOT, "A", iv_out=iv, flags_out=fl)
+    with torch.cuda.graph(graph):            # the first call on this grid is the captured one
+        grid.surface_static(p, SPOT, variant, iv_out=iv, flags_out=fl)
     for seed in (12, 13):
         p.copy_(_params(n, seed))
         graph.replay()
         torch.cuda.synchronize()
-        iv_ref, fl_ref, _ = grid.surface(p, SPOT, "A")
+        iv_ref, fl_ref, _ = grid.surface(p, SPOT, variant)
         assert _same(iv, iv_ref) and torch.equal(fl, fl_ref)
