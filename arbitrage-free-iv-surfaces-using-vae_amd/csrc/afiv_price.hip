@@ -30,6 +30,8 @@
 // tables that live in LDS beside the operand buffers; the per-strike and per-maturity constants
 // of the epilogue are staged there too, because the epilogue runs between two workgroup barriers
 // where no other wave's work covers a global load.
+#include <algorithm>
+
 #include "afiv_internal.h"
 #include "afiv_math.h"
 #include "laguerre144.inc"
@@ -254,10 +256,15 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert(NEVAL >= WAVES / 4, "one distinct MFMA slot per wave of a SIMD");
     const int nT = g.nT, nK = g.nK, nKpad = SYM ? g.nHpad : g.nKpad;   // nKpad: table row length
     const bool ct_live = 16 * ct < nKpad;
-    const int ntiles = (nT + MT - 1) / MT;
+    // Small batches split a chunk's maturity tiles over gridDim.y workgroups (NFAC == 0 only: there
+    // every maturity is evaluated on its own, so the split changes no bit of the result).
+    const int ntiles_all = (nT + MT - 1) / MT;
+    const int tiles_per_split = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int tile_lo = min((int)blockIdx.y * tiles_per_split, ntiles_all);
+    const int tile_hi = min(tile_lo + tiles_per_split, ntiles_all);
     const int64_t nchunks = (N + SPB - 1) / SPB;
     const int64_t my_chunks = blockIdx.x < nchunks ? (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int64_t total = my_chunks * ntiles;
+    const int64_t total = my_chunks * (tile_hi - tile_lo);
 
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
@@ -275,14 +282,14 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     JState st0 = {}, st1 = {};
     Cx ex0 = {}, ex1 = {}, fa0 = {}, fa1 = {}, fb0 = {}, fb1 = {};   // NFAC > 0: running 1 - exp(-d T), and 1 - exp(-d step) of the steps
     int64_t prev_chunk = 0, chunk = blockIdx.x;      // advanced with the tile counter: no division per step
-    int prev_tile = 0, tile = 0;
+    int prev_tile = tile_lo, tile = tile_lo;
 
     for (int64_t G = 0; G <= total; ++G) {
         const bool have_cur = G < total, have_prev = G > 0;
         double *xw = lds + (G & 1) * XBUF;                  // written by this step's phase 1
         double *xr = lds + ((G + 1) & 1) * XBUF;            // operand block of the previous step
 
-        if (have_cur && tile == 0) {
+        if (have_cur && tile == tile_lo) {
             int64_t s = chunk * SPB + sl;
             if (s >= N) s = N - 1;                           // spare lanes / ragged tail: never stored
             const double kappa = params[5 * s + 0], theta = params[5 * s + 1], sigma = params[5 * s + 2],
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         }
         prev_chunk = chunk;
         prev_tile = tile;
-        if (++tile == ntiles) {
-            tile = 0;
+        if (++tile == tile_hi) {
+            tile = tile_lo;
             chunk += gridDim.x;
         }
     }
@@ -532,7 +539,13 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     const int64_t chunks = (N + SPB - 1) / SPB;
     // one workgroup per CU is resident (LDS); a few waves of workgroups per CU balance the tail
     const int64_t blocks = chunks < 256 * 8 ? chunks : 256 * 8;
-    dim3 grid((unsigned)blocks), block(THREADS);
+    // Fewer workgroups than CUs: a call's time is one workgroup's walk through its surfaces'
+    // maturities, two per step.  Where maturities are evaluated independently (no stepped
+    // exponential) that walk is split over several workgroups per chunk of surfaces.
+    const int ntiles = (g.nT + MT - 1) / MT;
+    int64_t split = 1;
+    if (g.step_count == 0 && blocks < 128) split = std::min<int64_t>(ntiles, 256 / blocks);
+    dim3 grid((unsigned)blocks, (unsigned)split), block(THREADS);
 #define AFIV_LAUNCH_PRICE(NCT, NF, SY) \
     hipLaunchKernelGGL((price_kernel<NCT, NF, SY>), grid, block, 0, s, g, params, N, ratio_out)
 #define AFIV_LAUNCH_PRICE_NF(NCT, SY)                        \

@@ -353,6 +353,28 @@ def test_flags_out_of_the_wrong_shape_is_rejected(afiv, grid821):
     assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(grid821.implied_vol(ratio, SPOT, "A")))
 
 
+@pytest.mark.parametrize("nT", [1, 2, 7, 8, 33])
+def test_small_batches_split_maturities_without_changing_a_bit(afiv, nT):
+    """On lattices without a stepped exponential a small batch's maturities are split over several
+    workgroups per chunk of surfaces (more workgroups than the batch alone would fill).  Every
+    maturity is evaluated on its own there, so a small call must return, bit for bit, the rows a
+    large call returns for the same parameter sets."""
+    rng = np.random.default_rng(nT)
+    tau = np.sort(rng.uniform(0.02, 2.5, nT))                    # irregular: no stepping
+    grid = afiv.Grid(LOGM_GRID, tau, R, Q)
+    assert grid.traits["stepped"] == 0
+    p = dev(sample_params(3000, 21))
+    big = grid.price(p)
+    for n in (1, 6, 7, 8, 100, 700, 896, 903):                   # around the chunk size and the split limit
+        small = grid.price(p[:n].contiguous())
+        assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), n
+    # the whole path on a small batch
+    iv_b, fl_b, _ = grid.surface(p, SPOT, "A")
+    iv_s, fl_s, _ = grid.surface(p[:100].contiguous(), SPOT, "A")
+    assert torch.equal(torch.nan_to_num(iv_s, nan=-1.0), torch.nan_to_num(iv_b[:100], nan=-1.0))
+    assert torch.equal(fl_s, fl_b[:100])
+
+
 @pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
 def test_two_streams_share_one_grid(afiv, variant):
     """A grid object is immutable: implied-vol calls with different spots issued on two streams at
