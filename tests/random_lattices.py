@@ -66,7 +66,12 @@ def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_points=12):
     noisy side: the kernel is compared with a 60-digit evaluation of the same quadrature
     (oracle/exact.py) at up to ``max_exact_points`` of those points, still by the plain rule, and
     with the oracle only by the oracle's own noise bound.  Where the formula's value leaves the
-    double range both sides must agree on that."""
+    double range both sides must agree on that.  Where it leaves the range of prices -- beyond 1e3
+    in spot-1 units, a thousand times anything a call can be worth, which only the series form
+    reaches: there the value is the exponential of a sum whose terms reach 1e7, so its relative
+    accuracy is the ABSOLUTE accuracy of that sum, eight digits in any double-precision evaluation
+    (seed 30081: exact -2.744667e32, kernel 2.6e-8 off, oracle 2.9e-7 off) -- both sides must
+    agree that it did, and to 1e-6 relative."""
     from oracle import exact
     tol = price_tol(ref)
     noise = oracle_noise(p, tau) + 1e-4 * np.abs(ref) * (p[:, 2] <= 1e-5)[:, None, None]
@@ -85,6 +90,8 @@ def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_points=12):
             g = got[i, t, k]
             if wild(np.array(e)):
                 ok = bool(wild(np.array(g)))
+            elif abs(e) > 1e3:
+                ok = abs(g) > 1e3 and abs(g - e) <= 1e-6 * abs(e)
             else:
                 ok = abs(g - e) <= 1e-8 * max(abs(e), 1e-4)
             if not ok:

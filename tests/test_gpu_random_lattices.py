@@ -20,3 +20,13 @@ def test_random_lattices_match_oracle(afiv, first):
         except AssertionError as e:
             failures.append(f"seed {seed}: {c['desc']}: {e}")
     assert not failures, "\n".join(failures)
+
+
+@pytest.mark.parametrize("seed", [417, 30081])
+def test_trials_the_open_ended_sweep_once_failed(afiv, seed):
+    """Seeds tools/gpu_fuzz.py found outside the fixed range: 417 (1 - exp(-dT) formed by
+    subtraction lost 4e-12 at kappa = 0.01 and a three-day maturity: a kernel defect, fixed) and
+    30081 (series form at sigma_v = 1e-5 blowing up to -2.7e32, where no double evaluation has more
+    than eight digits: the sweep's rule, see random_lattices.price_bad)."""
+    oracle.set_threads(16)
+    run_case(afiv, make_case(seed))
