@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, gathers go through host memory)")
+    ap.add_argument("--solo-gather", action="store_true",
+                    help="with one rank: run the collective path all the same, as a one-rank RCCL group "
+                         "(rehearses the exchange code on a single GPU)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered flag words of the last step here (.npy)")
     args = ap.parse_args()
 
@@ -259,8 +262,12 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.solo_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -278,9 +285,14 @@ def main():
     # ranks' inputs is the same 1 048 576 rows whatever N is
     params = synthetic_params(total, 3, "cpu")[lo:hi].contiguous().to(device)
     ratio = torch.empty((n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
-    iv = torch.empty_like(ratio)
-    flags_local = torch.empty((n_local, 4), dtype=torch.int32, device=device)
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 or args.solo_gather) and not args.no_gather
+    # With a collective behind every chunk the local outputs are double-buffered: step i + 1 writes
+    # the other pair while RCCL still reads step i's, so the exchange of one step overlaps the
+    # kernels of the next (every step's gathers complete inside the timed region all the same).
+    nbuf = 2 if gather and args.backend == "nccl" else 1
+    iv_bufs = [torch.empty_like(ratio) for _ in range(nbuf)]
+    flags_bufs = [torch.empty((n_local, 4), dtype=torch.int32, device=device) for _ in range(nbuf)]
+    iv, flags_local = iv_bufs[0], flags_bufs[0]
     chunks = GATHER_CHUNKS if gather and n_local % GATHER_CHUNKS == 0 else 1
     rows = n_local // chunks
     if gather:
@@ -290,8 +302,16 @@ def main():
         flags_all = torch.empty((chunks, world, rows, 4), dtype=torch.int32, device=device)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * chunks + 1)] for _ in range(args.steps)]
 
+    in_flight = [[] for _ in range(nbuf)]      # collectives still reading each pair of local buffers
+    counter = [0]
+
     def step(events=None):
-        pending = []
+        b = counter[0] % nbuf
+        counter[0] += 1
+        iv, flags_local = iv_bufs[b], flags_bufs[b]
+        for w in in_flight[b]:                 # the step before last must have left these buffers
+            w.wait()
+        pending = in_flight[b] = []
         for c in range(chunks):
             sl = slice(c * rows, (c + 1) * rows)
             if events:
@@ -314,12 +334,17 @@ def main():
                     dst.copy_(host.view(dst.shape))
         if events:
             events[2 * chunks].record()
-        for w in pending:
-            w.wait()
+        if nbuf == 1:
+            for w in pending:
+                w.wait()
 
     def fence():
+        for works in in_flight:
+            for w in works:
+                w.wait()
+            works.clear()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -418,7 +443,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(logm, tau)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

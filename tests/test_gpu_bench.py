@@ -51,3 +51,21 @@ def test_launch_under_torch_distributed_run(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["surfaces_per_gpu_per_step"] == 1024
     assert "final_gather" in line and line["kernels_only"]["value"] > 0
     assert np.load(dump).shape == (2048, 4)
+
+
+def test_rccl_exchange_path_with_one_rank(tmp_path):
+    """The collective code itself -- asynchronous RCCL all-gathers behind every chunk, local outputs
+    double-buffered across steps, the fence, the stand-alone exchange timing -- run as a one-rank
+    RCCL group on the test box's GPU (two ranks cannot share a device under RCCL): three steps, so
+    both buffer pairs are reused, must leave the flag words of the plain run."""
+    one, flags1 = _bench(tmp_path, "plain")
+    cmd_extra = ("--solo-gather",)
+    dump = str(tmp_path / "solo.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--surfaces", "6144", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--dump", dump, *cmd_extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "all-gathered" in line["config"]["parallelism"] and line["final_gather"]["ms"] > 0
+    assert line["final_gather"]["bytes_per_rank"] == 6144 * (20 * 50 * 8 + 16)
+    assert np.array_equal(np.load(dump), flags1)
