@@ -20,9 +20,9 @@
 // workgroup advances in steps of 2 maturities: 7 surfaces x 2 maturities fill 14 of the 16 rows
 // of one MFMA row block.  Phase 1 of step G writes its 16 x 576 operand block into one half of a
 // double-buffered LDS area while phase 2 of step G-1 reads the other half: each wave owns one
-// (column tile, K range) of the contraction and issues its MFMA chain after a different one of
-// the step's four characteristic-function evaluations (waves w, w+4, w+8, w+12 share a SIMD), so
-// the chain's table loads and LDS reads are covered by the other waves' vector work.  B
+// (column tile, K range) of the contraction and issues its MFMA chain after the step's first or
+// second characteristic-function evaluation (waves w, w+4, w+8, w+12 share a SIMD: two chains at
+// a time), so the chain's table loads and LDS reads are covered by the other waves' vector work.  B
 // fragments stream from the L2-resident table through raw buffer loads (one offset register
 // instead of a 64-bit address pair per fragment), two batches in flight; partial tiles are
 // reduced through LDS in a fixed order (bitwise reproducible results).
@@ -250,10 +250,13 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     const int plane = wave & 3;
     const int ct = SYM ? (wave >> 2) % NCTP : wave % NCTP;
     const int kq = SYM ? (wave >> 2) / NCTP : wave / NCTP;
-    // waves w, w+4, ... share a SIMD: each issues its MFMA chain after a different one of the
-    // step's 2*MT characteristic-function evaluations
-    const int my_slot = (wave >> 2) * (NEVAL / (WAVES / 4));
-    static_assert(NEVAL >= WAVES / 4, "one distinct MFMA slot per wave of a SIMD");
+    // waves w, w+4, w+8, w+12 share a SIMD: two of them issue their MFMA chains after the step's
+    // first characteristic-function evaluation, the other two after the second.  A chain is a run
+    // of dependent accumulations; two of them at a time fill each other's issue gaps, and none is
+    // left for the end of the step, where no vector work would cover it (chains spread over all
+    // four evaluations: +1 %).
+    const int my_slot = (wave >> 2) & 1;
+    static_assert(NEVAL >= 2, "two MFMA slots");
     const int nT = g.nT, nK = g.nK, nKpad = SYM ? g.nHpad : g.nKpad;   // nKpad: table row length
     const bool ct_live = 16 * ct < nKpad;
     // Small batches split a chunk's maturity tiles over gridDim.y workgroups (NFAC == 0 only: there
