@@ -234,14 +234,18 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
                     } else {
                         // Householder's third-order step: nu (1 + g nu / 2) / (1 + g nu + d nu^2 / 6) with
                         // nu = -f/f', g = f''/f' = d1 d2 / sigma, d = f'''/f' = g^2 - (d1^2 + d1 d2 + d2^2)/sigma^2
-                        const double nu = -f * rcp_step(v);
-                        const double rs = rcp_step(sig);
+                        // -- multiplied through by (sigma f')^2, so that ONE reciprocal (a quarter-rate
+                        // instruction and its refinement) serves where nu, 1/sigma and the quotient took three:
+                        //   n sigma (a + dd n / 2) / (a^2 + dd n a + q n^2 / 6),   n = -f, a = sigma f', dd = d1 d2,
+                        //   q = dd^2 - d1^2 - dd - d2^2.  A vanishing vega gives 0/0: the bracket test below
+                        // sends the NaN to bisection.
+                        const double n = -f;
+                        const double a = sig * v;
                         const double dd = ax.d1 * ax.d2;
-                        const double gm = dd * rs;
-                        const double dl = gm * gm - (ax.d1 * ax.d1 + dd + ax.d2 * ax.d2) * (rs * rs);
-                        const double gn = gm * nu;
-                        const double num = nu * (1.0 + 0.5 * gn);
-                        const double den = 1.0 + gn + dl * (nu * nu) * (1.0 / 6.0);
+                        const double q = dd * dd - (ax.d1 * ax.d1 + dd + ax.d2 * ax.d2);
+                        const double tn = dd * n;
+                        const double num = (n * sig) * (a + 0.5 * tn);
+                        const double den = a * (a + tn) + q * ((n * n) * (1.0 / 6.0));
                         const double cand = sig + num * rcp_step(den);
                         sig = (cand > lo && cand < hi) ? cand : 0.5 * (lo + hi);
                     }
