@@ -289,12 +289,20 @@ __device__ __forceinline__ void load_atan_table(double *lds_tab)
     for (int i = threadIdx.x; i < ATAN_TAB_DOUBLES; i += blockDim.x) lds_tab[i] = c_atan_tab[i];
 }
 
+// atan2(y, x) given t = min(|x|,|y|) / max(|x|,|y|): the caller may have that quotient from a
+// reciprocal it needs anyway.
+__device__ __forceinline__ double atan2_tab_quot_f64(double y, double x, double t, const double *__restrict__ tab);
+
 __device__ __forceinline__ double atan2_tab_f64(double y, double x, const double *__restrict__ tab)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    return atan2_tab_quot_f64(y, x, fmin(ax, ay) * rcp_f64(fmax(ax, ay)), tab);
+}
+
+__device__ __forceinline__ double atan2_tab_quot_f64(double y, double x, double t, const double *__restrict__ tab)
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-    const double t = mn * rcp_f64(mx);
     const double shifted = __builtin_fma(t, 64.0, 0x1.8p52);   // low word = rint(64 t)
     const double kd = shifted - 0x1.8p52;
     const double h = __builtin_fma(kd, -0x1p-6, t);

@@ -179,11 +179,18 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         const Cx w1 = cmul(s.pq, omex);
         const double q = __builtin_fma(w1.r, w1.r, __builtin_fma(w1.i, w1.i, 2.0 * w1.r));   // |1 + w1|^2 - 1
         const double zr = 1.0 + w1.r;
-        const double inv = afivm::rcp_f64(1.0 + q);
+        // 1/|1 + w1|^2 and the arctangent's quotient min/max of (|zr|, |w1.i|) from ONE reciprocal
+        // (a quarter-rate instruction and two refinement steps): R = 1/(P mx), 1/P = R mx, 1/mx = R P
+        const double P = 1.0 + q;
+        const double ax = fabs(zr), ay = fabs(w1.i);
+        const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+        const double R = afivm::rcp_f64(P * mx);
+        const double inv = R * mx;
         const Cx wz = cmul(w1, Cx{zr * inv, -w1.i * inv});                                    // w1 / (1 + w1)
         const Cx f1 = cmul(s.sum, wz);
         const double glr = 0.5 * afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);
-        const double gli = afivm::atan2_tab_f64(w1.i, zr, sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
+        const double gli = afivm::atan2_tab_quot_f64(w1.i, zr, mn * (R * P),
+                                                    sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
         A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
     } else {
