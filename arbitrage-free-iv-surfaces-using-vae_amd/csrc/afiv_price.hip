@@ -186,12 +186,13 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         const double mx = fmax(ax, ay), mn = fmin(ax, ay);
         const double R = afivm::rcp_f64(P * mx);
         const double inv = R * mx;
-        const Cx wz = cmul(w1, Cx{zr * inv, -w1.i * inv});                                    // w1 / (1 + w1)
+        // w1 / (1 + w1) = w1 conj(1 + w1) / |1 + w1|^2 = (w1.r + |w1|^2, w1.i) / P, and |w1|^2 = q - 2 w1.r
+        const Cx wz = {(q - w1.r) * inv, w1.i * inv};
         const Cx f1 = cmul(s.sum, wz);
-        const double glr = 0.5 * afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);
+        const double gl2 = afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);          // 2 Re g = log |1 + w1|^2
         const double gli = afivm::atan2_tab_quot_f64(w1.i, zr, mn * (R * P),
                                                     sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
-        A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - 2.0 * glr);
+        A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - gl2);
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
     } else {
         const Cx pe = cmul(s.pq, Cx{1.0 - omex.r, -omex.i});
