@@ -188,12 +188,12 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         const double inv = R * mx;
         // w1 / (1 + w1) = w1 conj(1 + w1) / |1 + w1|^2 = (w1.r + |w1|^2, w1.i) / P, and |w1|^2 = q - 2 w1.r
         const Cx wz = {(q - w1.r) * inv, w1.i * inv};
-        const Cx f1 = cmul(s.sum, wz);
+        const Cx f1 = cmul(s.sum, wz);                     // s.sum carries the factor v0 / sigma^2 (see the kernel)
         const double gl2 = afivm::log1p_tab_f64(q, sct + afivm::SINCOS_TAB_DOUBLES);          // 2 Re g = log |1 + w1|^2
         const double gli = afivm::atan2_tab_quot_f64(w1.i, zr, mn * (R * P),
                                                     sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
-        A.r = m.c1 * f1.r + m.c2 * (s.a.r * T - gl2);
-        A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
+        A.r = f1.r + m.c2 * (s.a.r * T - gl2);
+        A.i = f1.i + m.c2 * (s.a.i * T - 2.0 * gli);
     } else {
         const Cx pe = cmul(s.pq, Cx{1.0 - omex.r, -omex.i});
         const Cx f1 = cmul(cmul(s.a, omex), crcp(Cx{1.0 - pe.r, -pe.i}));
@@ -311,6 +311,11 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             m.c2 = m.main_branch ? (kappa * theta) / m.sigma2 : kappa * theta;
             st0 = cf_setup<0>(kappa, sigma, rho, m, phi);
             st1 = cf_setup<1>(kappa, sigma, rho, m, phi);
+            if (m.main_branch) {
+                // t1 + d only ever multiplies w1 / (1 + w1) and v0 / sigma^2: fold the factor in once
+                st0.sum = {st0.sum.r * m.c1, st0.sum.i * m.c1};
+                st1.sum = {st1.sum.r * m.c1, st1.sum.i * m.c1};
+            }
             if (NFAC > 0) {
                 const double T0 = g.term[0];
                 ex0 = comex_neg(st0.d, T0, sct);
