@@ -43,6 +43,24 @@ __global__ __launch_bounds__(1024) void k(double *out, unsigned long long *ticks
         } else if (MODE == 7) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) a[j] = a[j] > c ? a[j] : m;               // v_cmp + 2 v_cndmask
+        } else if (MODE == 8) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = __builtin_rint(a[j] * m);           // v_mul + v_rndne_f64
+        } else if (MODE == 9) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = __builtin_amdgcn_fract(a[j] * m);   // v_mul + v_fract_f64
+        } else if (MODE == 10) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = __builtin_amdgcn_ldexp(a[j] * m, (int)b[j] & 1);   // v_mul + v_and + v_ldexp_f64
+        } else if (MODE == 11) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = (double)(int)(a[j] * m);            // v_mul + v_cvt_i32_f64 + v_cvt_f64_i32
+        } else if (MODE == 12) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = __builtin_amdgcn_sqrt(a[j]);        // v_sqrt_f64 (no refinement)
+        } else if (MODE == 13) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) b[j] = b[j] * (b[j] | 3u);                 // v_or + v_mul_lo_u32
         }
     }
     double s = acc[0] + acc[1] + acc[2] + acc[3];
@@ -93,6 +111,12 @@ int main()
     run<1>("u32 mul+add", out, ticks, 5 * iters, CH);
     run<5>("u32 xor, add", out, ticks, 5 * iters, 2 * CH);
     run<7>("f64 cmp+sel", out, ticks, 5 * iters, 3 * CH);
+    run<8>("mul, rndne", out, ticks, 5 * iters, 2 * CH);
+    run<9>("mul, fract", out, ticks, 5 * iters, 2 * CH);
+    run<10>("mul,and,ldexp", out, ticks, 5 * iters, 3 * CH);
+    run<11>("mul, 2 cvt", out, ticks, 5 * iters, 3 * CH);
+    run<12>("v_sqrt_f64", out, ticks, 2 * iters, CH);
+    run<13>("or, mul_lo_u32", out, ticks, 5 * iters, 2 * CH);
     (void)hipFree(out); (void)hipFree(ticks);
     return 0;
 }
