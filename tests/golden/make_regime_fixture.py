@@ -32,6 +32,7 @@ PT = f"{REF}/llm_options_assistant/best_model_2025/regime_samples/all_regimes_he
 T_GRID = np.array([0.08333333, 0.16666667, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
 LOGM_GRID = np.linspace(-0.2, 0.2, 21)
 ROWS_PER_REGIME = 64
+NOISE_LEVEL = 1e-12          # price ratio below which a point is the quadrature's rounding noise
 
 
 def read_regime_tensors(path):
@@ -95,27 +96,41 @@ def main():
     ns = reference_check_functions()
     spot, r, q = 21000.0, 0.067, 0.0                      # the script's defaults (:40-44)
     names, params, stats = [], [], []
+    per = {k: [] for k in ("valid", "static", "calendar", "free", "fragile")}
     for name, full in regimes.items():
         p32 = full[:ROWS_PER_REGIME]
         p = p32.astype(np.float64)                         # params[idx] elements widened by float() (:123)
-        _ratio, iv, _flags = oracle.surface_batch(p, LOGM_GRID, T_GRID, spot, r, q, "B")
+        ratio, iv, _flags = oracle.surface_batch(p, LOGM_GRID, T_GRID, spot, r, q, "B")
         valid = ~np.isnan(iv).any(axis=(1, 2))             # success = no NaN at all (:180)
-        static, calendar, free = [], [], 0
-        for s in iv[valid]:
-            res = ns["check_all_arbitrage"](s, T_GRID, LOGM_GRID, spot, r, q)
+        static = np.full(len(p), -1)
+        calendar = np.full(len(p), -1)
+        free = np.zeros(len(p), dtype=bool)
+        for i in np.nonzero(valid)[0]:
+            res = ns["check_all_arbitrage"](iv[i], T_GRID, LOGM_GRID, spot, r, q)
             if res is not None:
-                static.append(res["static_violations"])
-                calendar.append(res["calendar_violations"])
-                free += int(res["is_arbitrage_free"])
+                static[i] = res["static_violations"]
+                calendar[i] = res["calendar_violations"]
+                free[i] = bool(res["is_arbitrage_free"])
+        # A surface is FRAGILE if one of its price ratios is below NOISE_LEVEL: deep out of the money
+        # the true price is zero to double precision and the quadrature returns its own rounding
+        # noise (a few 1e-15 of either sign), so whether such a point has an implied vol -- and
+        # with it whether the surface counts as valid -- is decided by that noise and differs
+        # between any two double-precision evaluations of the same formula.
+        fragile = (np.abs(ratio) < NOISE_LEVEL).any(axis=(1, 2))
         n_valid = int(valid.sum())
-        stats.append([len(p), n_valid, free, float(np.mean(static)) if static else 0.0,
-                      float(np.mean(calendar)) if calendar else 0.0])
+        stats.append([len(p), n_valid, int(free.sum()), float(np.mean(static[valid])) if n_valid else 0.0,
+                      float(np.mean(calendar[valid])) if n_valid else 0.0])
         names.append(name)
         params.append(p32)
-        print(name, stats[-1], "kappa %.3g..%.3g rho %.3g..%.3g" % (p[:, 0].min(), p[:, 0].max(), p[:, 3].min(), p[:, 3].max()))
+        for k, v in (("valid", valid), ("static", static), ("calendar", calendar), ("free", free), ("fragile", fragile)):
+            per[k].append(v)
+        print(name, stats[-1], "fragile", int(fragile.sum()),
+              "kappa %.3g..%.3g rho %.3g..%.3g" % (p[:, 0].min(), p[:, 0].max(), p[:, 3].min(), p[:, 3].max()))
     np.savez_compressed(f"{HERE}/regime_fixture.npz", names=np.array(names), params=np.stack(params),
                         stats=np.array(stats), stats_columns=np.array(["n_total", "n_valid", "arbitrage_free_count",
                                                                        "avg_static_violations", "avg_calendar_violations"]),
+                        valid=np.stack(per["valid"]), static=np.stack(per["static"]), calendar=np.stack(per["calendar"]),
+                        free=np.stack(per["free"]), fragile=np.stack(per["fragile"]), noise_level=NOISE_LEVEL,
                         T_grid=T_GRID, logm_grid=LOGM_GRID, spot=spot, r=r, q=q)
 
 

@@ -253,33 +253,58 @@ def test_regime_functions_match_reference_outputs(mods, golden_dir):
     assert np.median(np.abs(iv[m] - ref_iv[m])) <= 1e-9
 
 
-def test_regime_statistics_reproduce_the_reference_loop_on_its_own_regime_parameters(mods, golden_dir):
+def test_regime_statistics_reproduce_the_reference_loop_on_its_own_regime_parameters(mods, afiv, golden_dir):
     """generate_regime_surfaces.py:296-362 on the first 64 parameter sets of each of the reference's
     eight regimes (best_model_2025/regime_samples/all_regimes_heston_params.pt, read statically by
     tests/golden/make_regime_fixture.py): valid surfaces, arbitrage-free count and the average
     static / calendar violation counts equal those of the oracle's variant-B surfaces checked by the
-    reference's own check_all_arbitrage; the surface statistics equal NumPy's on the oracle's vols."""
+    reference's own check_all_arbitrage; the surface statistics equal NumPy's on the oracle's vols.
+
+    Exact counts are asked of the surfaces whose every price ratio is above 1e-12.  Below that --
+    deep out of the money at the short end of the low-volatility regimes -- the true price is zero
+    to double precision, the quadrature returns its own rounding noise (a few 1e-15 of either
+    sign), and whether such a point has a variant-B implied vol, hence whether its surface counts
+    as valid, is decided by that noise: it differs between any two double-precision evaluations
+    (oracle 4.83e-15 -> vol 1.35, kernel 4.73e-15 -> NaN at one of them).  For those surfaces the
+    test asks that the NaN masks differ at noise points only."""
+    import torch
     R = mods["generate_regime_surfaces"]
     g = np.load(f"{golden_dir}/regime_fixture.npz")
     spot, r, q = float(g["spot"]), float(g["r"]), float(g["q"])
+    noise = float(g["noise_level"])
+    grid = afiv.Grid(g["logm_grid"], g["T_grid"], r, q)
     seen_partial = False
-    for name, p32, ref in zip(g["names"], g["params"], g["stats"]):
-        stats = R.regime_statistics(p32, g["T_grid"], g["logm_grid"], spot, r, q)
+    n_fragile = 0
+    for ri, (name, p32, ref) in enumerate(zip(g["names"], g["params"], g["stats"])):
+        robust = ~g["fragile"][ri]
+        n_fragile += int((~robust).sum())
+        valid = g["valid"][ri] & robust
+        want = [int(robust.sum()), int(valid.sum()), int(g["free"][ri][valid].sum()),
+                float(np.mean(g["static"][ri][valid])) if valid.any() else 0.0,
+                float(np.mean(g["calendar"][ri][valid])) if valid.any() else 0.0]
+        stats = R.regime_statistics(p32[robust], g["T_grid"], g["logm_grid"], spot, r, q)
         assert stats is not None, name
         got = [stats["n_total"], stats["n_valid"], stats["arbitrage_free_count"],
                stats["avg_static_violations"], stats["avg_calendar_violations"]]
-        assert got == list(ref), f"{name}: {got} != {list(ref)}"
-        assert stats["success_rate"] == ref[1] / ref[0] * 100
-        assert stats["arbitrage_free_pct"] == ref[2] / ref[1] * 100
-        seen_partial |= 0 < ref[1] < ref[0]
-        _ratio, iv_o, _ = oracle.surface_batch(p32.astype(np.float64), g["logm_grid"], g["T_grid"], spot, r, q, "B")
-        ok = ~np.isnan(iv_o).any(axis=(1, 2))
-        assert stats["surfaces"].shape == (int(ref[1]), 8, 21)
-        assert np.abs(stats["surfaces"] - iv_o[ok]).max() <= 1e-6
+        assert got == want, f"{name}: {got} != {want}"
+        assert stats["success_rate"] == want[1] / want[0] * 100
+        assert stats["arbitrage_free_pct"] == want[2] / want[1] * 100
+        seen_partial |= 0 < want[1] < want[0]
+        ratio_o, iv_o, _ = oracle.surface_batch(p32.astype(np.float64), g["logm_grid"], g["T_grid"], spot, r, q, "B")
+        assert np.array_equal(~np.isnan(iv_o).any(axis=(1, 2)), g["valid"][ri])          # the fixture's own surfaces
+        assert stats["surfaces"].shape == (want[1], 8, 21)
+        assert np.abs(stats["surfaces"] - iv_o[valid]).max() <= 1e-6
         for key, fn in (("mean_surface", np.mean), ("std_surface", np.std), ("median_surface", np.median)):
-            assert np.abs(stats[key] - fn(iv_o[ok], axis=0)).max() <= 1e-6
-        assert np.abs(stats["atm_iv_mean"] - iv_o[ok][:, :, 10].mean(axis=0)).max() <= 1e-6
-        assert np.abs(stats["p95_surface"] - np.percentile(iv_o[ok], 95, axis=0)).max() <= 1e-6
+            assert np.abs(stats[key] - fn(iv_o[valid], axis=0)).max() <= 1e-6
+        assert np.abs(stats["atm_iv_mean"] - iv_o[valid][:, :, 10].mean(axis=0)).max() <= 1e-6
+        assert np.abs(stats["p95_surface"] - np.percentile(iv_o[valid], 95, axis=0)).max() <= 1e-6
+        # every surface, fragile ones included: the kernel's NaN mask leaves the oracle's at noise points only
+        iv_g, _fl, _ra = grid.surface(torch.as_tensor(p32.astype(np.float64)).cuda(), spot, "B")
+        differ = np.isnan(iv_g.cpu().numpy()) != np.isnan(iv_o)
+        assert not (differ & (np.abs(ratio_o) >= noise)).any(), name
+        whole = R.regime_statistics(p32, g["T_grid"], g["logm_grid"], spot, r, q)
+        assert abs(whole["n_valid"] - int(ref[1])) <= int((~robust).sum())
+    assert 10 <= n_fragile <= 40                            # the rule above is the exception, not the test
     assert seen_partial                                     # some regime loses surfaces to NaN points
     assert R.regime_statistics(np.array([[2.0, 0.04, 0.3, -0.7, 0.04]]) * np.array([1, 1, 1, 1, -1.0]),
                                g["T_grid"], g["logm_grid"], spot, r, q) is None      # no valid surface at all
