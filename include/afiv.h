@@ -45,7 +45,7 @@ enum {
 /* Which Black-Scholes form is inverted / re-priced, and for the forward form how its root is
  * found.  The forward form's objective increases with the vol, so every convergent method lands
  * within the reference's xtol = 1e-6 of scipy.optimize.brentq's answer: AFIV_VARIANT_A uses a
- * closed-form first guess and Householder steps (two objective evaluations per point),
+ * closed-form first guess and Householder steps (one or two objective evaluations per point),
  * AFIV_VARIANT_A_BRENT walks brentq's own iteration path (about ten).  Both apply brentq's rules at
  * the bracket ends with the same arithmetic, so their NaN masks are identical.  The spot form's
  * objective is not monotone (the reference's sign convention), so it is always solved on brentq's
@@ -130,11 +130,13 @@ int afiv_arb_check(const afiv_grid *g, const double *iv, const double *ratio, in
 
 /* ---- implied vol and checks in one pass over the lattice: afiv_implied_vol followed by
  * afiv_arb_check(bs_form = variant, no mask), but each vol's re-priced Black-Scholes value is
- * taken from the root finder's last objective evaluation instead of being recomputed.  The vols
- * are identical to afiv_implied_vol's; the flag words are identical to the two-call sequence's
- * except where a price difference sits within rounding (1e-11) of its 1e-6 threshold: the two
- * evaluate the same formula with different roundings (one shared exponential and a reciprocal-based
- * quotient here, separate exponentials and an IEEE quotient there).  Replaces the body of generate_iv_surface plus check_all_arbitrage
+ * taken from the root finder instead of being recomputed: its last objective evaluation, or, where
+ * AFIV_VARIANT_A returns the vol a small final step lands on, the target price itself (within
+ * vega x 1e-9 of that vol's value).  The vols are identical to afiv_implied_vol's; the flag words are
+ * identical to the two-call sequence's except where a price difference sits that close to its 1e-6
+ * threshold (rounding, 1e-11, on the Brent-path variants: the two evaluate the same formula with
+ * different roundings -- one shared exponential and a reciprocal-based quotient here, separate
+ * exponentials and an IEEE quotient there).  Replaces the body of generate_iv_surface plus check_all_arbitrage
  * (generate_regime_surfaces.py:320-335 calls them back to back). */
 int afiv_implied_vol_checked(const afiv_grid *g, const double *ratio, int64_t N, double spot,
                              int variant, double *iv_out, int32_t *flags_out, void *stream);
