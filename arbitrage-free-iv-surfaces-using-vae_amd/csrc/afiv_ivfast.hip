@@ -256,8 +256,9 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
                         // derivative ratios: a step below 1e-3 with g step below 1e-2 lands within 1e-9 of
                         // the root, and the stepped-to vol is returned without a second evaluation.  Its
                         // Black-Scholes value for the checks is then the target price itself: they
-                        // differ by vega x 1e-9 at most, far inside the checks' 1e-6 tolerance in the
-                        // same units -- the reference re-prices brentq's vol, which is 2e-7 off.
+                        // differ by vega x 1e-9 at most (in practice by rounding: the typical step is
+                        // 1e-6 of the vol), where the reference's own re-priced value is vega x 2e-7
+                        // from the target -- brentq stops that far from the root.
                         const double dmax = fmax(ax.d1 * ax.d1, ax.d2 * ax.d2);
                         if (inside && fabs(step) <= 1e-3 && dmax * fabs(step) <= 1e-2 * sig) {
                             res = cand;
