@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _bench(tmp_path, tag, *extra):
     dump = str(tmp_path / f"{tag}.npy")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--surfaces", "6144", "--steps", "1", "--warmup", "1",
@@ -40,7 +47,7 @@ def test_launch_under_torch_distributed_run(tmp_path):
     size taken from the environment (two ranks on the one GPU, gloo)."""
     dump = str(tmp_path / "tdr.npy")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--backend", "gloo", "--surfaces", "2048", "--steps", "1", "--warmup", "0",
            "--no-cpu-baseline", "--dump", dump]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
