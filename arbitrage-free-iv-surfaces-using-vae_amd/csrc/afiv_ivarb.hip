@@ -484,83 +484,6 @@ __global__ __launch_bounds__(256) void penalty_kernel(GridView g, const double *
     if (threadIdx.x == 0) { acc_out[0] = ssum[0]; acc_out[1] = scnt[0]; }
 }
 
-// run_single_heston_calibration.py:252-287 for (candidate c, day d): the loss matrix is a
-// "distance matrix" between model rows and market rows, evaluated term by term in the reference's
-// order (no expansion of the squares: the RMSE is a 1e-3 remainder of numbers of size 1).
-// A workgroup owns 64 days x 32 candidates.  The lattice is walked in chunks of 128 points: the
-// chunk of the 64 market rows is staged in LDS (coalesced reads, rows padded to an odd stride so
-// that lanes = days read without bank conflicts), next to the chunk of the 32 model rows; a lane
-// keeps one day, a wave a quarter of the candidates, and every market value read from LDS serves
-// eight candidates whose partial sums stay in registers across the chunks.
-constexpr int S1_DAYS = 64, S1_CHUNK = 128, S1_GROUPS = 8, S1_WAVES = 4, S1_CANDS = S1_GROUPS * S1_WAVES;
-
-__global__ __launch_bounds__(64 * S1_WAVES) void stage1_kernel(GridView g, const double *__restrict__ model_ratio,
-                                                               const double *__restrict__ params, int64_t C,
-                                                               const double *__restrict__ market_ratio, int64_t D,
-                                                               double drift_weight, double *__restrict__ loss_out)
-{
-    __shared__ double mk[S1_DAYS][S1_CHUNK + 1];
-    __shared__ double md[S1_CANDS][S1_CHUNK];
-    __shared__ unsigned char atm[S1_CHUNK];
-    const int nK = g.nK, per = g.nT * nK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t d0 = (int64_t)blockIdx.x * S1_DAYS, c0 = (int64_t)blockIdx.y * S1_CANDS;
-    const double nan = __builtin_nan("");
-    double se[S1_GROUPS], sm_model[S1_GROUPS];
-    bool bad[S1_GROUPS];
-#pragma unroll
-    for (int q = 0; q < S1_GROUPS; ++q) { se[q] = 0.0; sm_model[q] = 0.0; bad[q] = false; }
-    double sm_mkt = 0.0;
-    int n = 0, n_atm = 0;
-    for (int p0 = 0; p0 < per; p0 += S1_CHUNK) {
-        const int len = min(S1_CHUNK, per - p0);
-        __syncthreads();
-        for (int idx = tid; idx < S1_DAYS * len; idx += 64 * S1_WAVES) {
-            const int dd = idx / len, i = idx - dd * len;
-            mk[dd][i] = d0 + dd < D ? market_ratio[(d0 + dd) * per + p0 + i] : nan;
-        }
-        for (int idx = tid; idx < S1_CANDS * len; idx += 64 * S1_WAVES) {
-            const int cc = idx / len, i = idx - cc * len;
-            md[cc][i] = c0 + cc < C ? model_ratio[(c0 + cc) * per + p0 + i] : 0.0;
-        }
-        for (int i = tid; i < len; i += 64 * S1_WAVES) atm[i] = fabs(g.logm[(p0 + i) % nK]) < 0.05 ? 1 : 0;
-        __syncthreads();
-        for (int i = 0; i < len; ++i) {
-            const double y = mk[lane][i];
-            if (isnan(y)) continue;                              // a point the reference drops (:185)
-            const bool a = atm[i] != 0;
-            n++;
-            if (a) { sm_mkt += y; n_atm++; }
-#pragma unroll
-            for (int q = 0; q < S1_GROUPS; ++q) {
-                const double m = md[q * S1_WAVES + wave][i];
-                if (isnan(m) || m < 0) bad[q] = true;
-                const double e = m - y;
-                se[q] += e * e;
-                if (a) sm_model[q] += m;
-            }
-        }
-    }
-    const int64_t d = d0 + lane;
-    if (d >= D) return;
-#pragma unroll
-    for (int q = 0; q < S1_GROUPS; ++q) {
-        const int64_t c = c0 + q * S1_WAVES + wave;
-        if (c >= C) continue;
-        const double kappa = params[5 * c + 0], theta = params[5 * c + 1], sigma = params[5 * c + 2];
-        const double feller = 5.0 * fmax(0.0, sigma * sigma - 2 * kappa * theta);
-        double loss;
-        if (n < 10) loss = nan;                                  // the reference skips such a day (:202-203)
-        else if (bad[q]) loss = 1e10;
-        else {
-            const double rmse = sqrt(se[q] / n);
-            const double drift = n_atm > 0 ? fabs(sm_model[q] / n_atm - sm_mkt / n_atm) : 0.0;
-            loss = rmse + drift_weight * drift + feller;
-        }
-        loss_out[c * D + d] = loss;
-    }
-}
-
 // Unit-test hook: the normal CDF used by the kernels above, element-wise.
 __global__ void debug_ndtr_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ out)
 {
@@ -676,17 +599,5 @@ int afiv_launch_arb_check(const GridView &g, const double *iv, const double *rat
 int afiv_launch_penalty(const GridView &g, const double *ratio, int64_t B, double *acc_out, hipStream_t s)
 {
     hipLaunchKernelGGL(penalty_kernel, dim3(1), dim3(256), 0, s, g, ratio, B, acc_out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-int afiv_launch_stage1(const GridView &g, const double *model_ratio, const double *params, int64_t C,
-                       const double *market_ratio, int64_t D, double drift_weight, double *loss_out,
-                       hipStream_t s)
-{
-    if (C <= 0 || D <= 0) return 0;
-    const int64_t by = (C + S1_CANDS - 1) / S1_CANDS, bx = (D + S1_DAYS - 1) / S1_DAYS;
-    if (by > 65535 || bx > 0x7fffffff) return AFIV_E_SHAPE;
-    hipLaunchKernelGGL(stage1_kernel, dim3((unsigned)bx, (unsigned)by), dim3(64 * S1_WAVES), 0, s, g, model_ratio,
-                       params, C, market_ratio, D, drift_weight, loss_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -232,8 +232,8 @@ def test_config4_stage1_loss_matrix(afiv, golden_dir):
 @pytest.mark.parametrize("nT,nK,n_cand,n_days", [(1, 12, 5, 3), (3, 5, 33, 65), (20, 50, 70, 130), (64, 64, 9, 64),
                                                  (8, 21, 1, 1), (2, 64, 32, 128)])
 def test_stage1_loss_matrix_on_other_lattices(afiv, nT, nK, n_cand, n_days):
-    """The loss-matrix kernel walks the lattice in 128-point chunks and tiles 64 days x 32 candidates:
-    lattices shorter and longer than a chunk, tile remainders in both directions, market rows with
+    """The loss-matrix kernel walks the lattice in 16-point passes and tiles 128 days x 32 candidates:
+    lattices shorter and longer than a pass, tile remainders in both directions, market rows with
     holes (dropped points, :185), days left with fewer than ten points (NaN: the reference skips
     them, :202-203), model rows holding a NaN or a negative ratio (1e10, :270-271) -- against the
     same formula in NumPy.  The model ratios are synthetic: only the objective is under test."""
