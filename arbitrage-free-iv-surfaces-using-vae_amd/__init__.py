@@ -10,9 +10,9 @@ Layout
              generate_iv_surface_by_date, generate_regime_surfaces)
 """
 from . import _lib                                           # noqa: F401
-from .api import (Grid, Decoder, debug_math, ensemble_stats, MAX_ENSEMBLE, VARIANTS, STATUS_ARB_FREE, STATUS_BUTTERFLY_FREE,   # noqa: F401
+from .api import (Grid, Decoder, debug_math, ensemble_stats, ENSEMBLE_ONE_SWEEP, VARIANTS, STATUS_ARB_FREE, STATUS_BUTTERFLY_FREE,   # noqa: F401
                   STATUS_VALID, STATUS_SUCCESS_A, STATUS_SUCCESS_B)
 from . import dist                                           # noqa: F401
 
-__all__ = ["Grid", "Decoder", "debug_math", "ensemble_stats", "MAX_ENSEMBLE", "dist", "VARIANTS", "STATUS_ARB_FREE", "STATUS_BUTTERFLY_FREE",
+__all__ = ["Grid", "Decoder", "debug_math", "ensemble_stats", "ENSEMBLE_ONE_SWEEP", "dist", "VARIANTS", "STATUS_ARB_FREE", "STATUS_BUTTERFLY_FREE",
            "STATUS_VALID", "STATUS_SUCCESS_A", "STATUS_SUCCESS_B"]

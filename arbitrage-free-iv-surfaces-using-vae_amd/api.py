@@ -72,7 +72,7 @@ class Grid:
 
     @property
     def traits(self) -> dict:
-        """{"half_strike": bool, "stepped": 0 | 1 | 2}: the pricing shortcuts this lattice takes
+        """{"half_strike": bool, "stepped": 0 | 1 | 2 | 3}: the pricing shortcuts this lattice takes
         (see afiv_grid_traits)."""
         hs, st = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.lib().afiv_grid_traits(self._h, ctypes.byref(hs), ctypes.byref(st)), "afiv_grid_traits")
@@ -265,7 +265,7 @@ class Grid:
         return torch.where(stage1_loss >= 1e10, torch.full_like(total, 1e10), total)
 
 
-MAX_ENSEMBLE = 16384
+ENSEMBLE_ONE_SWEEP = 16384     # afiv.h: larger ensembles take several sweeps over the stack (no size limit)
 STATIC_SCRATCH_DOUBLES = 4 * 1024 * 1024
 
 
@@ -279,8 +279,8 @@ def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torc
         raise TypeError("iv must be a CUDA float64 tensor [N, ...]")
     n = v.shape[0]
     points = v[0].numel()
-    if n < 1 or n > MAX_ENSEMBLE or points < 1:
-        raise ValueError(f"ensemble_stats takes 1..{MAX_ENSEMBLE} surfaces per call, got {n}")
+    if n < 1 or points < 1:
+        raise ValueError(f"ensemble_stats needs at least one surface and one grid point, got {tuple(v.shape)}")
     sel = None
     if select is not None:
         sel = select.to(device=v.device, dtype=torch.uint8).contiguous()
@@ -293,7 +293,8 @@ def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torc
     return out
 
 
-MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5, "expm1": 6, "cosm1": 7}
+MATH_OPS = {"exp": 0, "sincos": 1, "log1p": 2, "atan2": 3, "rcp": 4, "ndtr": 5, "expm1": 6, "cosm1": 7,
+            "exp_tab": 8, "expm1_tab": 9}
 
 
 def debug_math(op: str, x: torch.Tensor, y: torch.Tensor | None = None):
@@ -302,7 +303,7 @@ def debug_math(op: str, x: torch.Tensor, y: torch.Tensor | None = None):
     if x.dtype != torch.float64 or not x.is_cuda:
         raise TypeError("x must be a CUDA float64 tensor")
     out0 = torch.empty_like(x)
-    two = op in ("sincos", "expm1", "cosm1")
+    two = op in ("sincos", "expm1", "cosm1", "expm1_tab")
     out1 = torch.empty_like(x) if two else None
     if y is not None:
         y = y.contiguous()

@@ -98,7 +98,8 @@ try {
     const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
     const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
     const size_t n_order = ((size_t)nT * nK * sizeof(unsigned short) + 31) / 32 * 4;   // in doubles, 32-byte multiple
-    const size_t nd = n_const + n_order;
+    const size_t n_prog = AFIV_MAX_MATURITIES / 8;                                     // one byte per maturity
+    const size_t nd = n_const + n_order + n_prog;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
            *p_Dr = p_Dq + nT, *p_disc = p_Dr + nT, *p_fwd = p_disc + nT, *p_dq = p_fwd + nT,
@@ -231,6 +232,77 @@ try {
             v.step_dt[0] = (double)base / 365.0;
             v.step_dt[1] = (down ? -1.0 : 1.0) / 365.0;
             v.step_sel = sel;
+        }
+    }
+    unsigned char prog[AFIV_MAX_MATURITIES] = {0};
+    v.prog = reinterpret_cast<const unsigned char *>(dev + n_const + n_order);
+    if (trunc_days && v.step_count == 0 && nT >= 2) {
+        // Maturities that are sums of earlier ones: 1 - exp(-d (Tx + Ty)) = ox + oy - ox oy costs six
+        // instructions where a direct evaluation costs an exp and a sincos.  A thread can keep the
+        // previous maturity's value (P) and two saved ones (A, B); which values to save is chosen
+        // here, by dynamic programming over (A, B) = indices of the saved maturities, so that the
+        // number of direct evaluations is smallest.  Exact in whole days, so the result does not
+        // depend on rounding of the year fractions.
+        std::vector<long> days(nT);
+        bool ok = true;
+        for (int t = 0; t < nT; ++t) {
+            days[t] = (long)(tau[t] * 365.0);
+            if (days[t] <= 0) ok = false;            // expired or same-day maturities: leave the lattice to the direct path
+        }
+        if (ok) {
+            const int S = nT + 1;                      // slot states: 0 = empty, i + 1 = holds maturity i
+            const int INF = 1 << 20;
+            std::vector<int> cost((size_t)(nT + 1) * S * S, INF);
+            std::vector<unsigned char> how((size_t)(nT + 1) * S * S, 0);
+            std::vector<int> from((size_t)(nT + 1) * S * S, -1);
+            auto at = [&](int t, int a, int b) { return ((size_t)t * S + a) * S + b; };
+            cost[at(0, 0, 0)] = 0;
+            for (int t = 0; t < nT; ++t)
+                for (int a = 0; a < S; ++a)
+                    for (int b = 0; b < S; ++b) {
+                        const int c0 = cost[at(t, a, b)];
+                        if (c0 >= INF) continue;
+                        const long vp = t > 0 ? days[t - 1] : -1, va = a ? days[a - 1] : -1, vb = b ? days[b - 1] : -1;
+                        int op = 0;
+                        const long w = days[t];
+                        if (vp > 0 && vp + vp == w) op = 1;
+                        else if (vp > 0 && va > 0 && vp + va == w) op = 2;
+                        else if (vp > 0 && vb > 0 && vp + vb == w) op = 3;
+                        else if (va > 0 && va + va == w) op = 4;
+                        else if (va > 0 && vb > 0 && va + vb == w) op = 5;
+                        else if (vb > 0 && vb + vb == w) op = 6;
+                        const int c1 = c0 + (op == 0 ? 1 : 0);
+                        for (int save = 0; save < 3; ++save) {
+                            const int na = save == 1 ? t + 1 : a, nb = save == 2 ? t + 1 : b;
+                            const size_t j = at(t + 1, na, nb);
+                            if (c1 < cost[j]) {
+                                cost[j] = c1;
+                                how[j] = (unsigned char)(op | (save << 4));
+                                from[j] = a * S + b;
+                            }
+                        }
+                    }
+            int best = INF, ba = 0, bb = 0;
+            for (int a = 0; a < S; ++a)
+                for (int b = 0; b < S; ++b)
+                    if (cost[at(nT, a, b)] < best) { best = cost[at(nT, a, b)]; ba = a; bb = b; }
+            // worth a kernel of its own when at least a quarter of the direct evaluations go
+            if (best < INF && 4 * best <= 3 * nT) {
+                int a = ba, b = bb;
+                for (int t = nT; t > 0; --t) {
+                    const size_t j = at(t, a, b);
+                    prog[t - 1] = how[j];
+                    const int f = from[j];
+                    a = f / S;
+                    b = f % S;
+                }
+                // (the block is already on the device: this small piece follows it)
+                if (hipMemcpy(dev + n_const + n_order, prog, sizeof(prog), hipMemcpyHostToDevice) != hipSuccess) {
+                    if (g->workspace) (void)hipFree(g->workspace);
+                    (void)hipFree(dev); delete g; return AFIV_E_HIP;
+                }
+                v.step_count = 3;
+            }
         }
     }
     if (!trunc_days && nT >= 4 && nT <= 32) {
@@ -474,7 +546,7 @@ int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int6
                         double *stats_out, void *stream)
 {
     if (!iv || !stats_out) return AFIV_E_NULL;
-    if (N < 1 || N > AFIV_MAX_ENSEMBLE || points < 1 || points > (1 << 24)) return AFIV_E_SHAPE;
+    if (N < 1 || N > (int64_t)1 << 31 || points < 1 || points > (1 << 24)) return AFIV_E_SHAPE;
     return afiv_launch_ensemble(iv, select, N, (int)points, stats_out, as_stream(stream));
 }
 
@@ -482,7 +554,7 @@ int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double 
                     void *stream)
 {
     if (n < 0) return AFIV_E_SHAPE;
-    if (op < 0 || op > AFIV_MATH_COSM1) return AFIV_E_ARG;
+    if (op < 0 || op > AFIV_MATH_EXPM1_TAB) return AFIV_E_ARG;
     if (n == 0) return AFIV_OK;
     if (!x || !out0) return AFIV_E_NULL;
     if (op == AFIV_MATH_ATAN2 && !y) return AFIV_E_NULL;

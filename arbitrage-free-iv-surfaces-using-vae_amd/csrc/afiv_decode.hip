@@ -107,5 +107,5 @@ int afiv_launch_decode(const DecoderView &d, const float *z, const float *c, int
     int64_t blocks = tiles < 256 * 2 ? tiles : 256 * 2;
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, d, z, c, N, c_rows,
                        normalized_out, p32, p64);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

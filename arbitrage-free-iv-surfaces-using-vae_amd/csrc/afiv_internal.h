@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "afiv.h"
 
 #define AFIV_NQ_NODES 144                 // Gauss-Laguerre nodes (QuantLib's default order)
@@ -36,6 +38,13 @@ struct GridView {
     int step_count;
     double step_dt[2];
     unsigned long long step_sel;
+    // Whole-day term structures whose maturities are sums of earlier ones (the reference's own
+    // 30, 60, 91, 182, 273, 365, 547, 730 days: 60 = 30 + 30, 182 = 91 + 91, 273 = 182 + 91, ...):
+    // step_count = 3 and prog[t] says how 1 - exp(-d T_t) is obtained (afiv_price.hip, NFAC = 3).
+    // Low nibble: 0 = evaluated directly, else the product form of two earlier values, each the
+    // previous maturity's (P) or one of two saved ones (A, B): 1 = P P, 2 = P A, 3 = P B, 4 = A A,
+    // 5 = A B, 6 = B B.  High nibble: 1 / 2 = keep this maturity's value as A / B.
+    const unsigned char *prog;     // [nT rounded up to 8] device bytes
     const unsigned short *order;   // [nT*nK] lattice points by decreasing |log(F/K)|/sqrt(tau): the order
                                    // in which the implied-vol kernel hands points to lanes (points far
                                    // from the money need the most root-finder iterations; served first,
@@ -63,6 +72,27 @@ struct afiv_decoder {
     int device;
     void *block;
 };
+
+// Raising a kernel's dynamic-LDS limit is a per-function, per-device attribute (not an allocation).
+// It is set when a launch first needs more than the limit already raised for that kernel on the
+// current device, not on every launch: `raised` is the kernel's own table, one entry per device.
+#define AFIV_MAX_DEVICES 64
+#define AFIV_LDS_PER_CU (160 * 1024)      // gfx950
+struct DynLdsLimit { std::atomic<size_t> bytes[AFIV_MAX_DEVICES]; };
+inline int afiv_ensure_dynamic_lds(const void *kernel, size_t bytes, DynLdsLimit &raised)
+{
+    if (bytes <= 48 * 1024) return AFIV_OK;               // within the default limit
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AFIV_E_HIP;
+    if (dev < 0 || dev >= AFIV_MAX_DEVICES) return AFIV_E_ARG;
+    if (raised.bytes[dev].load(std::memory_order_acquire) >= bytes) return AFIV_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return AFIV_E_HIP;
+    // racing first launches set the attribute twice; the larger size is the one that stays recorded
+    size_t seen = raised.bytes[dev].load(std::memory_order_relaxed);
+    while (seen < bytes && !raised.bytes[dev].compare_exchange_weak(seen, bytes, std::memory_order_release)) {}
+    return AFIV_OK;
+}
 
 // Launchers implemented in the kernel translation units.
 int afiv_launch_price(const GridView &g, const double *params, int64_t N, double *ratio_out,

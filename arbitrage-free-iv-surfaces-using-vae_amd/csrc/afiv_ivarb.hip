@@ -502,7 +502,7 @@ int afiv_launch_debug_ndtr(const double *x, int64_t n, double *out, hipStream_t 
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(debug_ndtr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 namespace {
@@ -533,7 +533,7 @@ int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, dou
         // raising the dynamic-LDS limit is a per-function attribute, not an allocation
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
+            return AFIV_E_HIP;
     }
     // few, long-lived workgroups: each one tabulates the bracket ends of the whole lattice first
     int64_t blocks = (N + NG - 1) / NG;
@@ -541,7 +541,7 @@ int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, dou
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>), dim3((unsigned)blocks), dim3(THREADS), lds,
                        s, g, ratio, N, spot, iv_out, flags);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 template <int VARIANT, bool CHECKS>
@@ -593,11 +593,11 @@ int afiv_launch_arb_check(const GridView &g, const double *iv, const double *rat
         hipLaunchKernelGGL(arb_kernel<0>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out, mask_out);
     else
         hipLaunchKernelGGL(arb_kernel<1>, dim3((unsigned)blocks), dim3(ARB_THREADS), 0, s, g, iv, ratio, N, spot, flags_out, mask_out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 int afiv_launch_penalty(const GridView &g, const double *ratio, int64_t B, double *acc_out, hipStream_t s)
 {
     hipLaunchKernelGGL(penalty_kernel, dim3(1), dim3(256), 0, s, g, ratio, B, acc_out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

@@ -37,6 +37,10 @@ using namespace afivbs;
 
 constexpr int FAST_THREADS = 512;
 constexpr int FAST_WAVES = FAST_THREADS / 64;
+// A vol that a small final step lands on is returned unevaluated when its re-priced value is within
+// LAND_PRICE_ERR of the target price (which then stands in for it in the checks); a check whose two
+// values are closer than CLOSE_CALL to flipping is repeated with exactly re-priced values.
+constexpr double LAND_PRICE_ERR = 1e-8, CLOSE_CALL = 4e-8;
 constexpr int BACH_ROW = 8;                       // 5 coefficients padded to 32-byte rows
 constexpr int BACH_ROWS = AFIV_BACH_NSEG_A + AFIV_BACH_NSEG_B;
 static_assert(AFIV_BACH_NCOEF == 5, "bachelier table degree");
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(FAST_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, double spot,
                     double *__restrict__ iv_out, int32_t *__restrict__ flags)
 {
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     const int nT = g.nT, nK = g.nK, per = nT * nK;
     double *tab = dyn;                                                         // ERFCX_LDS
     FastMat *mat = reinterpret_cast<FastMat *>(tab + ERFCX_LDS);               // [64]
@@ -182,6 +186,7 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
         }
         int n_nan = 0, n_bad = 0, n_stat = 0, n_cal = 0;
         double p_prev = nan;                                 // re-priced values of the previous 64 points
+        unsigned long long landed_prev = 0;                  // ... and which of them are target prices of landed vols
         for (int b = 0; b < nbatch; ++b) {
             const int i = (b << 6) + lane;
             const bool live = i < per;
@@ -205,7 +210,7 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
             // brentq up to its loop
             const double fa = pe.x - hp, fb = pe.y - hp;
             double res = nan, pr = hp;
-            bool go = false;
+            bool go = false, landed = false;
             if (ok && !isnan(fa) && !isnan(fb)) {
                 if (fa == 0) res = xa;
                 else if (fb == 0) res = xb;
@@ -260,9 +265,15 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
                         // 1e-6 of the vol), where the reference's own re-priced value is vega x 2e-7
                         // from the target -- brentq stops that far from the root.
                         const double dmax = fmax(ax.d1 * ax.d1, ax.d2 * ax.d2);
-                        if (inside && fabs(step) <= 1e-3 && dmax * fabs(step) <= 1e-2 * sig) {
+                        const double as = fabs(step), gs = dmax * as;
+                        // ... and in PRICE units, so that the rule does not loosen as the spot grows (the
+                        // checks compare re-priced values against an absolute 1e-6): vega x that error,
+                        // v as (gs / sigma)^3, stays below LAND_PRICE_ERR
+                        const double s3 = (sig * sig) * sig, g3 = (gs * gs) * gs;
+                        if (inside && as <= 1e-3 && gs <= 1e-2 * sig && (v * as) * g3 <= LAND_PRICE_ERR * s3) {
                             res = cand;
                             pr = hp;
+                            landed = true;
                             go = false;
                         } else {
                             sig = inside ? cand : 0.5 * (lo + hi);
@@ -278,15 +289,56 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
                 }
                 // static: strikes k-1, k of one maturity; calendar: maturities t-1, t of one strike.
                 // The neighbours sit 1 and nK lattice points back: in this batch or the previous one.
-                const double p_cur = live ? pr : nan;
-                const double up1 = __shfl(p_cur, (lane + 63) & 63, 64);
-                const double last = __shfl(p_prev, 63, 64);   // (cross-lane reads stay outside the selects:
-                const double left = lane == 0 ? last : up1;   //  a read under a lane mask returns 0 for the others)
+                double p_cur = live ? pr : nan;
                 const int back = (lane - nK) & 63;
-                const double c_cur = __shfl(p_cur, back, 64), c_prev = __shfl(p_prev, back, 64);
-                const double below = lane >= nK ? c_cur : c_prev;
-                if (live && k >= 1 && left < p_cur - 1e-6) n_stat++;
-                if (live && t >= 1 && below > p_cur + 1e-6) n_cal++;
+                bool v_stat, v_cal, close;
+                auto compare = [&]() {
+                    const double up1 = __shfl(p_cur, (lane + 63) & 63, 64);
+                    const double last = __shfl(p_prev, 63, 64);   // (cross-lane reads stay outside the selects:
+                    const double left = lane == 0 ? last : up1;   //  a read under a lane mask returns 0 for the others)
+                    const double c_cur = __shfl(p_cur, back, 64), c_prev = __shfl(p_prev, back, 64);
+                    const double below = lane >= nK ? c_cur : c_prev;
+                    const bool hs = live && k >= 1, hc = live && t >= 1;
+                    // left < p_cur - 1e-6 and below > p_cur + 1e-6 as the signs of two differences (a
+                    // difference of doubles has the sign of the comparison), whose sizes say how far
+                    // each comparison is from flipping
+                    const double ds = (p_cur - 1e-6) - left, dc = below - (p_cur + 1e-6);
+                    v_stat = hs && ds > 0;
+                    v_cal = hc && dc > 0;
+                    close = (hs && fabs(ds) <= CLOSE_CALL) || (hc && fabs(dc) <= CLOSE_CALL);
+                };
+                compare();
+                const unsigned long long landed_now = __ballot(landed);
+                if (__ballot(close) && (landed_now | landed_prev)) {
+                    // A comparison sits within CLOSE_CALL of its threshold and one of the two values
+                    // may be a target price standing in for the Black-Scholes value of a landed vol
+                    // (they differ by LAND_PRICE_ERR at most): re-price the landed vols of this batch
+                    // and the previous one exactly and compare again.  Rare: the whole wave takes it.
+                    auto reprice = [&](int idx, double vol) {
+                        const int tt = small_div(idx, inv_nK), kk = idx - __mul24(tt, nK);
+                        const FastMat mm = mat[tt];
+                        const d2v ff = fk[idx];
+                        BsPoint cc;
+                        cc.tau = mm.tau;
+                        cc.sqrt_tau = mm.sqrt_tau;
+                        cc.disc = mm.disc;
+                        cc.F = mm.F;
+                        cc.K = strike[kk];
+                        cc.lnFK = ff.x;
+                        cc.ratio = ff.y;
+                        return bs_objective<AFIV_VARIANT_A>(cc, vol, tab, ec);
+                    };
+                    const double e_cur = reprice(ic, landed ? res : 0.5);
+                    if (landed) p_cur = e_cur;
+                    const bool was = b > 0 && ((landed_prev >> lane) & 1ull);
+                    const int ip = was ? i - 64 : 0;
+                    const double e_prev = reprice(ip, was ? dst[ip] : 0.5);     // this lane's own store of the last batch
+                    if (was) p_prev = e_prev;
+                    compare();
+                }
+                landed_prev = landed_now;
+                if (v_stat) n_stat++;
+                if (v_cal) n_cal++;
                 if (live && (isnan(y) || y < 0)) skip_t[t] = 1;         // benign race: all writers store 1
                 if (live && k + 2 < nK) {
                     const double bf = y - 2 * src[i + 1] + src[i + 2];  // the same cache lines as y
@@ -323,6 +375,11 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
     }
 }
 
+constexpr size_t FAST_STATIC_LDS = 2 * sizeof(int) * FAST_WAVES * AFIV_MAX_MATURITIES;   // fly_all, skip_all
+static_assert((sizeof(FastMat) * AFIV_MAX_MATURITIES) % 16 == 0 && sizeof(FastMat) % 8 == 0,
+              "the arrays behind mat[] in dynamic LDS stay 16-byte aligned");
+static_assert((ERFCX_LDS * sizeof(double)) % 16 == 0 && (AFIV_MAX_STRIKES * sizeof(double)) % 16 == 0, "LDS sub-array offsets");
+
 size_t fast_lds_bytes(const GridView &g)
 {
     const size_t per = (size_t)g.nT * g.nK;
@@ -335,12 +392,10 @@ int launch_fast(const GridView &g, const double *ratio, int64_t N, double spot, 
                 hipStream_t s)
 {
     const size_t lds = fast_lds_bytes(g);
-    if (lds > 48 * 1024) {
-        // raising the dynamic-LDS limit is a per-function attribute, not an allocation
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&iv_fast_kernel<CHECKS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
-    }
+    if (lds + FAST_STATIC_LDS > AFIV_LDS_PER_CU) return AFIV_E_SHAPE;
+    static DynLdsLimit raised;
+    if (const int rc = afiv_ensure_dynamic_lds(reinterpret_cast<const void *>(&iv_fast_kernel<CHECKS>), lds, raised))
+        return rc;
     // long-lived workgroups (each tabulates the bracket ends of the lattice first), a wave per surface;
     // sixteen rounds of workgroups per CU: surfaces differ in their share of NaN points, and shorter
     // workgroups even that out (four rounds: +2 %), while the tables still cost under 1 %
@@ -348,7 +403,7 @@ int launch_fast(const GridView &g, const double *ratio, int64_t N, double spot, 
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL((iv_fast_kernel<CHECKS>), dim3((unsigned)blocks), dim3(FAST_THREADS), lds, s, g, ratio, N, spot,
                        iv_out, flags);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 }  // namespace

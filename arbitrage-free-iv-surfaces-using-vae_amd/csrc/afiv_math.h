@@ -155,6 +155,64 @@ __device__ __forceinline__ double exp_core_f64(double x, const ExpCoef &k)
     return __builtin_ldexp(p, (int)n);
 }
 
+// exp(x) through a 128-entry table in LDS: x = (128 m + j) ln(2)/128 + r with |r| <= ln(2)/256,
+// exp x = 2^m T_j (1 + w), w = exp r - 1 by the Taylor polynomial to r^5 -- 16 vector instructions
+// and one LDS read against 22 for the degree-13 form, and a dependent chain a third as long.  The
+// table holds 2^(j/128) as (hi, lo); the plain exponential uses hi alone (relative error 1 ulp).
+// Same limits as exp_core_f64: graceful underflow to 0, +inf above the range, NaN for a NaN.
+// `tab` is EXP_TAB_DOUBLES doubles filled by load_exp_table.
+constexpr int EXP_TAB_DOUBLES = 256;
+inline __constant__ __attribute__((aligned(16))) double c_exp_tab[EXP_TAB_DOUBLES] = {AFIV_EXP_TAB_LIST};
+
+__device__ __forceinline__ void load_exp_table(double *lds_tab)
+{
+    for (int i = threadIdx.x; i < EXP_TAB_DOUBLES; i += blockDim.x) lds_tab[i] = c_exp_tab[i];
+}
+
+// w = exp(r) - 1 for the reduced argument, and the table index / binary exponent of x
+__device__ __forceinline__ double exp_tab_reduce(double x, int *j, int *m)
+{
+    // k = rint(128 x / ln 2) by the shift trick: the sum's low mantissa bits hold k in two's complement
+    const double shifted = __builtin_fma(x, AFIV_128_OVER_LN2, 0x1.8p52);
+    const double k = shifted - 0x1.8p52;
+    double r = __builtin_fma(k, -AFIV_LN2O128_HI, x);
+    r = __builtin_fma(k, -AFIV_LN2O128_LO, r);
+    const int ki = __double2loint(shifted);
+    *j = ki & 127;
+    *m = ki >> 7;
+    const coef_ptr c_exp = coeffs(r) + OFF_EXP;                 // 1/2, 1/6, 1/24, 1/120: the Taylor coefficients
+    double p = c_exp[5];
+    p = fma_sc(p, r, c_exp[4]);
+    p = fma_sc(p, r, c_exp[3]);
+    p = fma_sc(p, r, c_exp[2]);
+    return __builtin_fma(p, r, 1.0) * r;
+}
+
+__device__ __forceinline__ double exp_tab_f64(double x, const double *__restrict__ tab)
+{
+    int j, m;
+    const double w = exp_tab_reduce(x, &j, &m);
+    const double th = tab[2 * j];
+    return __builtin_ldexp(__builtin_fma(th, w, th), m);
+}
+
+// exp(x) and exp(x) - 1 together, the latter without cancellation: with s = 2^m,
+// exp x - 1 = (s T_hi - 1) + s (T_hi w + T_lo), where s T_hi - 1 is exact whenever the two are
+// within a factor 2 (and elsewhere nothing cancels), and for m = j = 0 it is w itself.
+// Relative error 2 ulp for every x, x -> 0 included.
+__device__ __forceinline__ double exp_expm1_tab_f64(double x, const double *__restrict__ tab, double *em1)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int j, m;
+    const double w = exp_tab_reduce(x, &j, &m);
+    const d2 t = reinterpret_cast<const d2 *>(tab)[j];
+    const double v = __builtin_fma(t.x, w, t.y);
+    const double s = __builtin_ldexp(1.0, m);
+    const double ts = t.x * s, vs = v * s;
+    *em1 = (ts - 1.0) + vs;
+    return ts + vs;
+}
+
 template <bool PINNED = true>
 __device__ __forceinline__ double exp_f64(double x)
 {

@@ -31,6 +31,7 @@
 // of the epilogue are staged there too, because the epilogue runs between two workgroup barriers
 // where no other wave's work covers a global load.
 #include <algorithm>
+#include <cstdlib>
 
 #include "afiv_internal.h"
 #include "afiv_math.h"
@@ -60,7 +61,12 @@ constexpr int XBUF = ROWS * XSTRIDE;       // doubles per operand buffer
 static_assert(SPB * MT <= ROWS && SPB * NQ <= THREADS, "row / lane layout");
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int FTAB_DOUBLES = afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES + afivm::ATAN_TAB_DOUBLES;   // function tables in LDS
+// function tables in LDS: sincos | log | atan | exp
+constexpr int EXP_TAB_AT = afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES + afivm::ATAN_TAB_DOUBLES;
+constexpr int FTAB_DOUBLES = EXP_TAB_AT + afivm::EXP_TAB_DOUBLES;
+#ifndef AFIV_EXP_TABLE
+#define AFIV_EXP_TABLE 1
+#endif
 
 __constant__ double c_lag_x[NQ] = {AFIV_LAG_X_LIST};
 __constant__ double c_lag_wp[NQ] = {AFIV_LAG_WP_LIST};   // W_n / (pi x_n)
@@ -153,7 +159,11 @@ __device__ __forceinline__ JState cf_setup(double kappa, double sigma, double rh
 __device__ __forceinline__ Cx comex_neg(Cx d, double T, const double *__restrict__ sct)
 {
     double em1, sn, cs, cm1;
+#if AFIV_EXP_TABLE
+    const double er = afivm::exp_expm1_tab_f64(-d.r * T, sct + EXP_TAB_AT, &em1);
+#else
     const double er = afivm::exp_expm1_f64(-d.r * T, &em1);
+#endif
     afivm::sincos_cm1_tab_f64(d.i * T, sct, &sn, &cs, &cm1);
     return {-__builtin_fma(er, cm1, em1), er * sn};
 }
@@ -163,6 +173,36 @@ __device__ __forceinline__ Cx comex_step(Cx o, Cx f)
 {
     return {__builtin_fma(-o.r, f.r, __builtin_fma(o.i, f.i, o.r + f.r)),
             __builtin_fma(-o.r, f.i, __builtin_fma(-o.i, f.r, o.i + f.i))};
+}
+
+// NFAC = 3: one step of the lattice's program (GridView::prog) for one integral.  p = the previous
+// maturity's 1 - exp(-d T), a / b = the two saved ones; op is wave-uniform.
+__device__ __forceinline__ void prog_step(unsigned op, Cx &p, Cx &a, Cx &b, Cx d, double T,
+                                          const double *__restrict__ sct)
+{
+    Cx r;
+    switch (op & 15u) {
+        case 1: r = comex_step(p, p); break;
+        case 2: r = comex_step(p, a); break;
+        case 3: r = comex_step(p, b); break;
+        case 4: r = comex_step(a, a); break;
+        case 5: r = comex_step(a, b); break;
+        case 6: r = comex_step(b, b); break;
+        default: r = comex_neg(d, T, sct); break;
+    }
+    p = r;
+    // Wave-uniform branches around the copies.  (The empty asm statements keep them branches: as
+    // plain conditional assignments through the references the compiler selects the ADDRESS and
+    // moves a and b to scratch memory; as selects on the values they cost eight instructions at
+    // every maturity.)
+    if ((op >> 4) == 1u) {
+        a = r;
+        asm volatile("" : "+v"(a.r), "+v"(a.i));
+    }
+    if ((op >> 4) == 2u) {
+        b = r;
+        asm volatile("" : "+v"(b.r), "+v"(b.i));
+    }
 }
 
 // One characteristic-function evaluation given omex = 1 - exp(-d T): returns (E sin alpha,
@@ -202,7 +242,11 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
         A.i = m.c1 * f1.i + m.c2 * (s.a.i * T - 2.0 * gl.i / m.sigma2);
     }
     const double alpha = A.i + phi * ddt;
+#if AFIV_EXP_TABLE
+    const double E = wp * afivm::exp_tab_f64(A.r, sct + EXP_TAB_AT) * disc;
+#else
     const double E = wp * afivm::exp_core_f64(A.r) * disc;
+#endif
     double sa, ca;
     afivm::sincos_tab_f64(alpha, sct, &sa, &ca);
     return make_double2(E * sa, E * ca);
@@ -220,6 +264,13 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
 // o = 1 - exp(-d T) (comex_neg, comex_step: o' = o + f - o f with f = 1 - exp(-d step)), so that
 // the small quantity the characteristic function needs is never a difference of two numbers near
 // 1.  Some 40 steps add rounding of a few eps to a value that is evaluated to 2 ulp otherwise.
+//
+// NFAC = 3: whole-day maturities that are sums of earlier ones (the reference's own term structure):
+// 1 - exp(-d T_t) follows from two earlier values by the same product form, as the grid's program
+// says; the thread keeps the previous maturity's value and two saved ones in the registers that hold
+// the step factors of NFAC = 2.  A workgroup that starts in the middle of the term structure (small
+// batches split their maturities over several workgroups) first replays the program's earlier
+// steps, exponentials only, so its results are those of an unsplit walk bit for bit.
 //
 // SYM: the strikes are symmetric about the forward-free money line (log K_k = -log K_{nK-1-k}, as
 // in linspace(-a, a, n)), so cos(x log K) is shared and sin(x log K) only changes sign between a
@@ -267,8 +318,9 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert(NEVAL >= 2, "two MFMA slots");
     const int nT = g.nT, nK = g.nK, nKpad = SYM ? g.nHpad : g.nKpad;   // nKpad: table row length
     const bool ct_live = 16 * ct < nKpad;
-    // Small batches split a chunk's maturity tiles over gridDim.y workgroups (NFAC == 0 only: there
-    // every maturity is evaluated on its own, so the split changes no bit of the result).
+    // Small batches split a chunk's maturity tiles over gridDim.y workgroups (NFAC == 0, where every
+    // maturity is evaluated on its own, and NFAC == 3, which replays the steps it skipped: the split
+    // changes no bit of the result).
     const int ntiles_all = (nT + MT - 1) / MT;
     const int tiles_per_split = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int tile_lo = min((int)blockIdx.y * tiles_per_split, ntiles_all);
@@ -280,6 +332,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
     afivm::load_atan_table(sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
+    afivm::load_exp_table(sct + EXP_TAB_AT);
     if (tid < nK) ecst[0][tid] = g.Kmult[tid];
     if (tid < nT) {
         ecst[1][tid] = g.Dq[tid];
@@ -316,7 +369,18 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                 st0.sum = {st0.sum.r * m.c1, st0.sum.i * m.c1};
                 st1.sum = {st1.sum.r * m.c1, st1.sum.i * m.c1};
             }
-            if (NFAC > 0) {
+            if (NFAC == 3) {
+                typedef const unsigned __attribute__((address_space(4))) *prog_ptr;
+                const prog_ptr pw = (prog_ptr)(unsigned long long)(const void *)g.prog;
+                const afivm::coef_ptr tm = (afivm::coef_ptr)(unsigned long long)(const void *)g.term;
+                for (int t = 0; t < tile_lo * MT; ++t) {
+                    const unsigned op = (pw[t >> 2] >> (8 * (t & 3))) & 0xffu;
+                    const double T = tm[t];
+                    prog_step(op, ex0, fa0, fb0, st0.d, T, sct);
+                    prog_step(op, ex1, fa1, fb1, st1.d, T, sct);
+                }
+            }
+            if (NFAC == 1 || NFAC == 2) {
                 const double T0 = g.term[0];
                 ex0 = comex_neg(st0.d, T0, sct);
                 ex1 = comex_neg(st1.d, T0, sct);
@@ -378,18 +442,25 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         };
         // per-maturity constants (wave-uniform -> scalar registers), fetched one maturity ahead
         // (term, dd, Dq, Dr are consecutive [nT] arrays of the grid block: one base pointer)
-        const double *__restrict__ mc = g.term;
+        // read through the constant address space: the grid block is immutable, and wave-uniform
+        // loads from there are scalar loads into scalar registers (as plain global pointers they
+        // are vector loads of 64 identical values, waited for at the top of every maturity)
+        const afivm::coef_ptr mc = (afivm::coef_ptr)(unsigned long long)(const void *)g.term;
+        typedef const unsigned __attribute__((address_space(4))) *prog_ptr;
+        const prog_ptr progw = (prog_ptr)(unsigned long long)(const void *)g.prog;
 #pragma unroll 1
         for (int tl = 0; tl < MT; ++tl) {
             const int t = tile * MT + tl;
             const int tc = min(t, nT - 1);
             const double T = mc[tc], ddt = mc[nT + tc], Dq = mc[2 * nT + tc], Dr = mc[3 * nT + tc];
             // extra days on top of the base step that lead to maturity t (wave-uniform)
-            const int extra = NFAC > 1 ? (int)((g.step_sel >> (2 * t)) & 3ull) : 0;
+            const int extra = NFAC == 2 ? (int)((g.step_sel >> (2 * t)) & 3ull) : 0;
+            const unsigned op = NFAC == 3 ? (progw[tc >> 2] >> (8 * (tc & 3))) & 0xffu : 0u;
             if (have_cur) {
                 double2 x0 = make_double2(0.0, 0.0);
                 if (t < nT) {
                     if (NFAC == 0) ex0 = comex_neg(st0.d, T, sct);
+                    else if (NFAC == 3) prog_step(op, ex0, fa0, fb0, st0.d, T, sct);
                     else if (t > 0) {
                         ex0 = comex_step(ex0, fa0);
                         for (int e = 0; e < extra; ++e) ex0 = comex_step(ex0, fb0);
@@ -414,6 +485,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                 double2 x1 = make_double2(0.0, 0.0);
                 if (t < nT) {
                     if (NFAC == 0) ex1 = comex_neg(st1.d, T, sct);
+                    else if (NFAC == 3) prog_step(op, ex1, fa1, fb1, st1.d, T, sct);
                     else if (t > 0) {
                         ex1 = comex_step(ex1, fa1);
                         for (int e = 0; e < extra; ++e) ex1 = comex_step(ex1, fb1);
@@ -517,6 +589,7 @@ __global__ void debug_math_kernel(int op, const double *__restrict__ x, const do
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
     afivm::load_atan_table(sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES);
+    afivm::load_exp_table(sct + EXP_TAB_AT);
     __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double a = 0.0, b = 0.0;
@@ -527,6 +600,8 @@ __global__ void debug_math_kernel(int op, const double *__restrict__ x, const do
             case 3: a = afivm::atan2_tab_f64(x[i], y[i], sct + afivm::SINCOS_TAB_DOUBLES + afivm::LOG_TAB_DOUBLES); break;
             case 4: a = afivm::rcp_f64(x[i]); break;
             case 6: b = afivm::exp_expm1_f64(x[i], &a); break;                    // out0 = exp(x) - 1, out1 = exp(x)
+            case 8: a = afivm::exp_tab_f64(x[i], sct + EXP_TAB_AT); break;
+            case 9: b = afivm::exp_expm1_tab_f64(x[i], sct + EXP_TAB_AT, &a); break;   // out0 = exp(x) - 1, out1 = exp(x)
             case 7: { double sn, cs; afivm::sincos_cm1_tab_f64(x[i], sct, &sn, &cs, &a); b = cs; break; }   // cos(x) - 1, cos(x)
             default: break;
         }
@@ -544,23 +619,28 @@ int afiv_launch_debug_math(int op, const double *x, const double *y, int64_t n, 
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)blocks), dim3(256), 0, s, op, x, y, n, out0, out1);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 int afiv_launch_price(const GridView &g, const double *params, int64_t N, double *ratio_out, hipStream_t s)
 {
     if (N <= 0) return 0;
     const int nct = g.nKpad / 16;
-    if (nct < 1 || nct > 4) return -2;
+    if (nct < 1 || nct > 4) return AFIV_E_SHAPE;
     const int64_t chunks = (N + SPB - 1) / SPB;
-    // one workgroup per CU is resident (LDS); a few waves of workgroups per CU balance the tail
-    const int64_t blocks = chunks < 256 * 8 ? chunks : 256 * 8;
+    // One workgroup per CU is resident (LDS).  A workgroup's walk ends with one step that only
+    // drains the pipeline (the last tile's contraction and epilogue), and a batch ends when the
+    // last workgroup does: with fewer than 64 chunks per CU both are worth more than the dynamic
+    // balancing of many short workgroups, so each CU gets ONE workgroup and an equal share of the
+    // chunks (50 000 surfaces on 8 x 21: 1.09 -> ms); large batches keep eight rounds of workgroups.
+    int64_t blocks = chunks < 256 * 64 ? std::min<int64_t>(chunks, 256) : 256 * 8;
+    if (const char *e = getenv("AFIV_PRICE_BLOCKS")) blocks = std::min<int64_t>(chunks, atoi(e));
     // Fewer workgroups than CUs: a call's time is one workgroup's walk through its surfaces'
     // maturities, two per step.  Where maturities are evaluated independently (no stepped
     // exponential) that walk is split over several workgroups per chunk of surfaces.
     const int ntiles = (g.nT + MT - 1) / MT;
     int64_t split = 1;
-    if (g.step_count == 0 && blocks < 128) split = std::min<int64_t>(ntiles, 256 / blocks);
+    if ((g.step_count == 0 || g.step_count == 3) && blocks < 128) split = std::min<int64_t>(ntiles, 256 / blocks);
     dim3 grid((unsigned)blocks, (unsigned)split), block(THREADS);
 #define AFIV_LAUNCH_PRICE(NCT, NF, SY) \
     hipLaunchKernelGGL((price_kernel<NCT, NF, SY>), grid, block, 0, s, g, params, N, ratio_out)
@@ -568,6 +648,7 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     do {                                                     \
         if (g.step_count == 1) AFIV_LAUNCH_PRICE(NCT, 1, SY); \
         else if (g.step_count == 2) AFIV_LAUNCH_PRICE(NCT, 2, SY); \
+        else if (g.step_count == 3) AFIV_LAUNCH_PRICE(NCT, 3, SY); \
         else AFIV_LAUNCH_PRICE(NCT, 0, SY);                  \
     } while (0)
     if (g.sym) {
@@ -578,5 +659,5 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     else AFIV_LAUNCH_PRICE_NF(4, false);
 #undef AFIV_LAUNCH_PRICE_NF
 #undef AFIV_LAUNCH_PRICE
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

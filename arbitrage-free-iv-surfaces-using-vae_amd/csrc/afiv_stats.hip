@@ -111,6 +111,306 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__
     }
 }
 
+// ---- ensembles larger than one LDS-resident column ---------------------------------------------
+// The same four statistics, bit for bit, for any number of surfaces, without scratch memory.  One
+// workgroup owns TILE_P adjacent grid points (one 64-byte line of every surface row) and streams
+// the stack several times:
+//   sweep 1   count of usable values, their sum in sample order (the order NumPy adds the rows of a
+//             leading axis in, so the mean is np.nanmean's), and the smallest / largest value;
+//   sweep 2.. order statistics by narrowing: the median and the two percentiles need six ranks of the
+//             sorted column.  Values map to order-preserving 64-bit keys; every rank keeps a key
+//             interval [lo, lo + 2^shift) known to contain it plus the number of values below lo,
+//             starting from the common prefix of the smallest and largest key.  A sweep builds a
+//             256-bin histogram of each distinct interval (LDS atomics) and every rank moves into
+//             the bin that holds it -- eight key bits per sweep -- until its interval holds at most
+//             SEL_CAP values (or a single key);
+//   last      the values of the remaining intervals are collected in LDS and each rank is picked by
+//             counting: value v is the k-th smallest iff #(values < v) <= k < #(values <= v).
+// Selection is exact, so the interpolated statistics equal NumPy's whatever its partition does.
+// Three sweeps for 50 000 surfaces, four for a million; each reads every value once, coalesced.
+constexpr int TILE_P = 8;
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_ROWS = SEL_THREADS / TILE_P;     // rows per sweep step
+constexpr int SEL_BLOCK = 8 * SEL_ROWS;            // rows staged per block of the in-order sum
+constexpr int SEL_BINS = 256;
+constexpr int SEL_TARGETS = 6;
+constexpr int SEL_CAP = 256;
+
+__device__ __forceinline__ unsigned long long order_key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct SelTarget {
+    unsigned long long lo;    // interval [lo, lo + 2^shift); shift = 64: every key
+    long long below;          // values with key < lo
+    long long count;          // values inside the interval
+    long long rank;           // 0-based rank in the sorted column
+    int shift;
+    int alias;                // first target of this point with the same interval (its histogram / list is used)
+    int done;                 // 1: `value` is final
+    double value;
+};
+
+__device__ __forceinline__ bool in_interval(unsigned long long key, unsigned long long lo, int shift)
+{
+    return shift >= 64 ? true : ((key - lo) >> shift) == 0 && key >= lo;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const double *__restrict__ iv,
+                                                                      const uint8_t *__restrict__ select, int64_t N,
+                                                                      int per, double *__restrict__ out)
+{
+    // histograms [TILE_P][SEL_TARGETS][SEL_BINS] u32 (48 KB), later candidate lists
+    // [TILE_P][SEL_TARGETS][SEL_CAP] doubles (96 KB); the in-order sum's staging block shares it
+    __shared__ __attribute__((aligned(16))) unsigned char pool[TILE_P * SEL_TARGETS * SEL_CAP * sizeof(double)];
+    __shared__ SelTarget tg[TILE_P][SEL_TARGETS];
+    __shared__ unsigned long long kmin[TILE_P], kmax[TILE_P];
+    __shared__ long long cnt[TILE_P];
+    __shared__ double sum[TILE_P];
+    __shared__ int list_n[TILE_P][SEL_TARGETS];
+    __shared__ int again;
+    unsigned *hist = reinterpret_cast<unsigned *>(pool);
+    double *cand = reinterpret_cast<double *>(pool);
+    double *stage = reinterpret_cast<double *>(pool);          // [SEL_BLOCK][TILE_P], NaN = skip
+    const int tid = threadIdx.x, pt = tid & (TILE_P - 1), rl = tid / TILE_P;
+    const double nan = __builtin_nan("");
+
+    for (int p0 = blockIdx.x * TILE_P; p0 < per; p0 += gridDim.x * TILE_P) {
+        const int p = p0 + pt;
+        const bool have_p = p < per;
+        __syncthreads();
+        if (tid < TILE_P) { kmin[tid] = ~0ull; kmax[tid] = 0ull; cnt[tid] = 0; sum[tid] = 0.0; }
+        __syncthreads();
+
+        // ---- sweep 1: count, in-order sum, extremes
+        unsigned long long mn = ~0ull, mx = 0ull;
+        long long c = 0;
+        for (int64_t base = 0; base < N; base += SEL_BLOCK) {
+#pragma unroll
+            for (int u = 0; u < SEL_BLOCK / SEL_ROWS; ++u) {
+                const int64_t i = base + u * SEL_ROWS + rl;
+                double x = nan;
+                if (have_p && i < N && (!select || select[i])) x = iv[i * per + p];
+                stage[(u * SEL_ROWS + rl) * TILE_P + pt] = x;
+                if (x == x) {
+                    const unsigned long long k = order_key(x);
+                    mn = k < mn ? k : mn;
+                    mx = k > mx ? k : mx;
+                    ++c;
+                }
+            }
+            __syncthreads();
+            if (tid < TILE_P) {
+                double sacc = sum[tid];
+                const int rows = (int)(N - base < SEL_BLOCK ? N - base : SEL_BLOCK);
+                for (int r = 0; r < rows; ++r) {
+                    const double x = stage[r * TILE_P + tid];
+                    if (x == x) sacc += x;
+                }
+                sum[tid] = sacc;
+            }
+            __syncthreads();
+        }
+        if (c) {
+            atomicMin(&kmin[pt], mn);
+            atomicMax(&kmax[pt], mx);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&cnt[pt]), (unsigned long long)c);
+        }
+        __syncthreads();
+
+        // ---- ranks wanted: median (one or two middle values), 5th and 95th percentile neighbours
+        if (tid < TILE_P) {
+            const long long m = cnt[tid];
+            long long ranks[SEL_TARGETS] = {0, 0, 0, 0, 0, 0};
+            if (m > 0) {
+                ranks[0] = (m & 1) ? m / 2 : m / 2 - 1;
+                ranks[1] = m / 2;
+                for (int q = 0; q < 2; ++q) {
+                    // numpy "linear": virtual index (m - 1) q, neighbours floor and floor + 1 (clamped)
+                    const double virt = (double)(m - 1) * (q == 0 ? 5.0 / 100.0 : 95.0 / 100.0);
+                    long long ip, in;
+                    if (virt >= (double)(m - 1)) ip = in = m - 1;
+                    else if (virt < 0.0) ip = in = 0;
+                    else { ip = (long long)floor(virt); in = ip + 1; }
+                    ranks[2 + 2 * q] = ip;
+                    ranks[3 + 2 * q] = in;
+                }
+            }
+            const unsigned long long diff = kmin[tid] ^ kmax[tid];
+            const int sh = m > 0 ? (diff ? 64 - __clzll((long long)diff) : 0) : 0;
+            for (int j = 0; j < SEL_TARGETS; ++j) {
+                SelTarget t;
+                t.shift = sh;
+                t.lo = sh >= 64 ? 0ull : (kmin[tid] >> sh) << sh;
+                t.below = 0;
+                t.count = m;
+                t.rank = ranks[j];
+                t.alias = 0;
+                t.done = m == 0 || sh == 0;
+                t.value = m == 0 ? nan : key_value(kmin[tid]);
+                tg[tid][j] = t;
+            }
+        }
+        __syncthreads();
+
+        // ---- narrowing sweeps
+        for (;;) {
+            if (tid == 0) again = 0;
+            for (int i = tid; i < TILE_P * SEL_TARGETS * SEL_BINS; i += SEL_THREADS) hist[i] = 0u;
+            __syncthreads();
+            if (tid < TILE_P * SEL_TARGETS) {
+                const int q = tid / SEL_TARGETS, j = tid - q * SEL_TARGETS;
+                if (!tg[q][j].done && tg[q][j].count > SEL_CAP) again = 1;
+            }
+            __syncthreads();
+            if (!again) break;
+            // this point's intervals still to be narrowed (aliases removed), in registers
+            unsigned long long lo[SEL_TARGETS];
+            int sh[SEL_TARGETS];
+            int nsel = 0, slot[SEL_TARGETS];
+            for (int j = 0; j < SEL_TARGETS; ++j) {
+                const SelTarget &t = tg[pt][j];
+                if (!t.done && t.count > SEL_CAP && t.alias == j) {
+                    lo[nsel] = t.lo;
+                    sh[nsel] = t.shift;
+                    slot[nsel] = j;
+                    ++nsel;
+                }
+            }
+            for (int64_t base = 0; base < N; base += SEL_ROWS) {
+                const int64_t i = base + rl;
+                if (have_p && i < N && (!select || select[i])) {
+                    const double x = iv[i * per + p];
+                    if (x == x) {
+                        const unsigned long long k = order_key(x);
+                        for (int a = 0; a < nsel; ++a)
+                            if (in_interval(k, lo[a], sh[a])) {
+                                const int down = sh[a] > 8 ? sh[a] - 8 : 0;
+                                const unsigned bin = (unsigned)((k - lo[a]) >> down) & (SEL_BINS - 1);
+                                atomicAdd(&hist[(pt * SEL_TARGETS + slot[a]) * SEL_BINS + bin], 1u);
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < TILE_P * SEL_TARGETS) {
+                const int q = tid / SEL_TARGETS, j = tid - q * SEL_TARGETS;
+                SelTarget t = tg[q][j];
+                if (!t.done && t.count > SEL_CAP) {
+                    const unsigned *h = hist + (q * SEL_TARGETS + t.alias) * SEL_BINS;
+                    const int down = t.shift > 8 ? t.shift - 8 : 0;
+                    long long seen = t.below;
+                    int b = 0;
+                    for (; b < SEL_BINS - 1; ++b) {
+                        if (seen + (long long)h[b] > t.rank) break;
+                        seen += h[b];
+                    }
+                    t.lo += (unsigned long long)b << down;
+                    t.below = seen;
+                    t.count = h[b];
+                    t.shift = down;
+                    if (down == 0) { t.done = 1; t.value = key_value(t.lo); }     // a single key: that is the value
+                    tg[q][j] = t;
+                }
+            }
+            __syncthreads();
+            if (tid < TILE_P) {      // intervals have moved: find the aliases again
+                for (int j = 0; j < SEL_TARGETS; ++j) {
+                    int a = j;
+                    for (int i = 0; i < j; ++i)
+                        if (tg[tid][i].lo == tg[tid][j].lo && tg[tid][i].shift == tg[tid][j].shift) { a = i; break; }
+                    tg[tid][j].alias = a;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- last sweep: collect the values of the remaining intervals, pick the ranks by counting
+        if (tid < TILE_P * SEL_TARGETS) list_n[tid / SEL_TARGETS][tid % SEL_TARGETS] = 0;
+        __syncthreads();
+        {
+            unsigned long long lo[SEL_TARGETS];
+            int sh[SEL_TARGETS];
+            int nsel = 0, slot[SEL_TARGETS];
+            for (int j = 0; j < SEL_TARGETS; ++j) {
+                const SelTarget &t = tg[pt][j];
+                if (!t.done && t.alias == j) {
+                    lo[nsel] = t.lo;
+                    sh[nsel] = t.shift;
+                    slot[nsel] = j;
+                    ++nsel;
+                }
+            }
+            if (nsel)
+                for (int64_t base = 0; base < N; base += SEL_ROWS) {
+                    const int64_t i = base + rl;
+                    if (have_p && i < N && (!select || select[i])) {
+                        const double x = iv[i * per + p];
+                        if (x == x) {
+                            const unsigned long long k = order_key(x);
+                            for (int a = 0; a < nsel; ++a)
+                                if (in_interval(k, lo[a], sh[a])) {
+                                    const int at = atomicAdd(&list_n[pt][slot[a]], 1);
+                                    if (at < SEL_CAP) cand[(pt * SEL_TARGETS + slot[a]) * SEL_CAP + at] = x;
+                                }
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // one (point, rank) per group of 4 threads... simply: every thread takes candidates of one target in turn
+        for (int item = tid; item < TILE_P * SEL_TARGETS * SEL_CAP; item += SEL_THREADS) {
+            const int e = item % SEL_CAP, qj = item / SEL_CAP, q = qj / SEL_TARGETS, j = qj - q * SEL_TARGETS;
+            const SelTarget &t = tg[q][j];
+            if (t.done) continue;
+            const int n = list_n[q][t.alias];
+            if (e >= n) continue;
+            const double *lst = cand + (q * SEL_TARGETS + t.alias) * SEL_CAP;
+            const double v = lst[e];
+            int less = 0, leq = 0;
+            for (int i = 0; i < n; ++i) {
+                const double w = lst[i];
+                less += w < v;
+                leq += w <= v;
+            }
+            const long long k = t.rank - t.below;
+            if (less <= k && k < leq) tg[q][j].value = v;      // every writer stores the same value
+        }
+        __syncthreads();
+        if (tid < TILE_P && p0 + tid < per) {
+            const long long m = cnt[tid];
+            const int o = p0 + tid;
+            if (m == 0) {
+                out[0 * per + o] = out[1 * per + o] = out[2 * per + o] = out[3 * per + o] = nan;
+            } else {
+                out[0 * per + o] = sum[tid] / (double)m;
+                const double a = tg[tid][0].value, b = tg[tid][1].value;
+                out[1 * per + o] = (m & 1) ? b : (a + b) / 2.0;
+                for (int q = 0; q < 2; ++q) {
+                    // numpy's _get_gamma and _lerp on the two neighbours
+                    const double virt = (double)(m - 1) * (q == 0 ? 5.0 / 100.0 : 95.0 / 100.0);
+                    double prev = floor(virt);
+                    if (virt >= (double)(m - 1)) prev = -1.0;
+                    else if (virt < 0.0) prev = 0.0;
+                    const double gamma = virt - prev;
+                    const double lo_v = tg[tid][2 + 2 * q].value, hi_v = tg[tid][3 + 2 * q].value;
+                    const double diff = hi_v - lo_v;
+                    double r = lo_v + diff * gamma;
+                    if (gamma >= 0.5) r = hi_v - diff * (1.0 - gamma);
+                    out[(2 + q) * per + o] = r;
+                }
+            }
+        }
+    }
+}
+
 // ---- density-Wasserstein term of the calibration's second stage -------------------------------
 // run_single_heston_calibration.py:100-151 for every (candidate, day, maturity).  Both sides go
 // through the same steps -- second differences of the price ratios on the fine strike grid,
@@ -233,21 +533,24 @@ int afiv_launch_density_wasserstein(const GridView &g, const double *model_ratio
     const int64_t blocks = C < 4096 ? C : 4096;
     hipLaunchKernelGGL(wasserstein_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, cdf_model, st_model, C, cdf_market,
                        st_market, D, dist);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
 int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
                          hipStream_t s)
 {
+    if (N > AFIV_ENSEMBLE_ONE_SWEEP) {
+        const int tiles = (per + TILE_P - 1) / TILE_P;
+        hipLaunchKernelGGL(ensemble_select_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(SEL_THREADS), 0, s,
+                           iv, select, N, per, out);
+        return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
+    }
     int padded = 2;
     while (padded < N) padded <<= 1;
     const size_t lds = (size_t)padded * sizeof(double);
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ensemble_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
-    }
+    static DynLdsLimit raised;
+    if (const int rc = afiv_ensure_dynamic_lds(reinterpret_cast<const void *>(&ensemble_kernel), lds, raised)) return rc;
     hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)(per < 65536 ? per : 65536)), dim3(STAT_THREADS), lds, s, iv, select, N, per, padded,
                        out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

@@ -41,12 +41,15 @@ DEFAULT_UNREST_INDEX = 100.457836
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-def generate_iv_surfaces(params, T_grid, logm_grid, spot, r, q, variant="A", return_flags=False):
+def generate_iv_surfaces(params, T_grid, logm_grid, spot, r, q, variant="A", return_flags=False,
+                         on_device=False):
     """Batched generate_iv_surface: ``params`` is [N,5] (NumPy or torch, any float dtype; values
     are widened to float64 exactly as ``float(x)`` does at :286).
 
     Returns ``(iv [N,nT,nK] float64 ndarray with NaN, success [N] bool ndarray)`` and, with
-    ``return_flags``, the [N,4] int32 flag words (static, calendar, butterfly, status)."""
+    ``return_flags``, the [N,4] int32 flag words (static, calendar, butterfly, status).  With
+    ``on_device`` the three are CUDA tensors and nothing crosses to the host: ``success`` then goes
+    straight into ``ensemble_statistics`` as its selection mask."""
     if isinstance(params, torch.Tensor):
         p = params.detach().to("cuda", torch.float64)
     else:
@@ -54,13 +57,13 @@ def generate_iv_surfaces(params, T_grid, logm_grid, spot, r, q, variant="A", ret
     p = p.reshape(-1, 5).contiguous()
     grid = cached_grid(logm_grid, T_grid, r, q)
     iv, flags, _ratio = grid.surface(p, float(spot), variant)
-    iv_np = iv.cpu().numpy()
-    flags_np = flags.cpu().numpy()
     bit = _afiv.STATUS_SUCCESS_A if variant in ("A", 0, "A_BRENT", 2) else _afiv.STATUS_SUCCESS_B
-    success = (flags_np[:, 3] & bit) != 0
+    success = (flags[:, 3] & bit) != 0
+    if not on_device:
+        iv, success, flags = iv.cpu().numpy(), success.cpu().numpy(), flags.cpu().numpy()
     if return_flags:
-        return iv_np, success, flags_np
-    return iv_np, success
+        return iv, success, flags
+    return iv, success
 
 
 def generate_iv_surface(params, T_grid, logm_grid, spot, r, q):
@@ -82,11 +85,18 @@ def decode_parameters(model, z, conditioning_batch, param_mean, param_std):
     return model.decode_parameters(z, conditioning_batch, param_mean, param_std)
 
 
-def ensemble_statistics(surfaces):
+def ensemble_statistics(surfaces, success=None):
     """nan-aware mean / median / 5th / 95th percentile over valid surfaces (:474-478), computed on
-    the GPU with NumPy's arithmetic (np.nanmean, np.nanmedian, np.nanpercentile "linear")."""
-    s = torch.as_tensor(np.ascontiguousarray(np.asarray(surfaces, dtype=np.float64)), device="cuda")
-    out = _afiv.ensemble_stats(s).cpu().numpy()
+    the GPU with NumPy's arithmetic (np.nanmean, np.nanmedian, np.nanpercentile "linear"), for any
+    number of surfaces.  ``surfaces`` is the stack of valid surfaces (NumPy, as the reference
+    builds it at :470) or a CUDA tensor of ALL surfaces together with their ``success`` mask
+    (``generate_iv_surfaces(..., on_device=True)``), in which case the vols never leave the device:
+    only the four (nT, nK) result surfaces come back."""
+    if isinstance(surfaces, torch.Tensor) and surfaces.is_cuda:
+        s = surfaces.to(torch.float64)
+    else:
+        s = torch.as_tensor(np.ascontiguousarray(np.asarray(surfaces, dtype=np.float64)), device="cuda")
+    out = _afiv.ensemble_stats(s, success).cpu().numpy()
     return out[0], out[1], out[2], out[3]
 
 
@@ -177,13 +187,13 @@ def main(argv=None):
     print(f" Generated {len(params_np)} parameter sets")
 
     print("\nGenerating IV surfaces...")
-    iv, success = generate_iv_surfaces(params64, T_GRID, LOGM_GRID, args.spot, args.r, args.q)
-    surfaces_array = iv[success]
-    if len(surfaces_array) == 0:
+    iv, success = generate_iv_surfaces(params64, T_GRID, LOGM_GRID, args.spot, args.r, args.q, on_device=True)
+    n_ok = int(success.sum())
+    if n_ok == 0:
         print(" No valid surfaces generated!")
         return 1
-    stats = ensemble_statistics(surfaces_array)
-    n_ok = len(surfaces_array)
+    stats = ensemble_statistics(iv, success)          # on the device, the success bits as the selection mask
+    surfaces_array = iv[success].cpu().numpy()        # only for the saved file (:495-508 stores them)
     print(f" Valid surfaces: {n_ok}/{args.n_samples} ({n_ok / args.n_samples * 100:.1f}%)")
     print(f"  Mean IV (overall):   {np.nanmean(stats[0]) * 100:.2f}%")
 

@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X: half of the 157.3 TFLOP/s FP32 vector peak
+HBM_PEAK_GBPS = 8000.0             # MI355X HBM3E
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8    # one of a GPU's seven xGMI links (153.6 GB/s both ways)
 N_STRIKES, N_MATURITIES = 50, 20
 SPOT, R, Q = 21000.0, 0.067, 0.0
 TOTAL_SURFACES = 1048576           # BASELINE.json configs[2]
@@ -52,6 +54,39 @@ def iv_checks_flops(n_t: int, n_k: int) -> float:
 
 def surface_flops(n_t: int, n_k: int) -> float:
     return pricing_flops(n_t, n_k) + iv_checks_flops(n_t, n_k)
+
+
+def iv_checks_bytes(n_t: int, n_k: int) -> float:
+    """Algorithmic HBM bytes of the implied-vol + checks kernel per surface: every price ratio read
+    once, every vol written once, one 16-byte flag word."""
+    return 8.0 * n_t * n_k * 2 + 16.0
+
+
+def kernel_sources_sha() -> str:
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h, *.inc): counter summaries under
+    profiles/ carry the fingerprint of the sources they were measured on, and are quoted only
+    while it still matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "arbitrage-free-iv-surfaces-using-vae_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                       glob.glob(os.path.join(csrc, "*.inc"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def general_lattice():
+    """A 50-strike x 20-maturity lattice that qualifies for neither pricing shortcut: unevenly spaced
+    strikes (no half-strike contraction) and whole-day maturities without a common step or sums
+    (every exponential evaluated directly)."""
+    import numpy as np
+    rng = np.random.default_rng(50)
+    logm = np.sort(rng.uniform(-0.2, 0.2, N_STRIKES))
+    days = np.array([30, 61, 95, 133, 171, 208, 251, 288, 331, 362, 401, 443, 470, 517, 549, 580, 623, 661, 697, 730])
+    return logm, (days + 0.5) / 365.0
 
 
 def synthetic_params(n: int, seed: int, device):
@@ -134,7 +169,12 @@ def launch_ranks(n: int) -> int:
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # RCCL maps its peers' buffers through HIP IPC handles.  On hosts whose driver offers only
+        # dmabuf-based IPC (the MI355X pool this was built on exports the variable for that reason)
+        # the legacy handle type fails in hipIpcGetMemHandle with "invalid argument", so the ranks
+        # get the dmabuf mode unless the caller's environment already chose one.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
@@ -232,7 +272,13 @@ def main():
                     help="total surfaces per step over all ranks (default: the configured 1 048 576)")
     ap.add_argument("--config", type=int, default=3, help="1, 2 or 4: time another BASELINE.json workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="leave vols and flags sharded (no collective at all)")
+    ap.add_argument("--no-general-lattice", action="store_true",
+                    help="skip the extra passes on a lattice without the pricing shortcuts (N = 1)")
+    ap.add_argument("--gather", default=None, choices=["all", "flags", "none"],
+                    help="what a step's final exchange carries at N > 1: 'all' = implied vols and flag words "
+                         "(the configured workload, default), 'flags' = the 16-byte flag words only, vols stay "
+                         "sharded for consumers that reduce on the device, 'none' = no collective at all")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, gathers go through host memory)")
@@ -285,7 +331,9 @@ def main():
     # ranks' inputs is the same 1 048 576 rows whatever N is
     params = synthetic_params(total, 3, "cpu")[lo:hi].contiguous().to(device)
     ratio = torch.empty((n_local, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
-    gather = (world > 1 or args.solo_gather) and not args.no_gather
+    mode = args.gather or ("none" if args.no_gather else "all")
+    gather = (world > 1 or args.solo_gather) and mode != "none"
+    gather_vols = gather and mode == "all"
     # With a collective behind every chunk the local outputs are double-buffered: step i + 1 writes
     # the other pair while RCCL still reads step i's, so the exchange of one step overlaps the
     # kernels of the next (every step's gathers complete inside the timed region all the same).
@@ -298,16 +346,19 @@ def main():
     if gather:
         # gathered per chunk: [chunk][rank][rows of that chunk]; row r of rank q's chunk c is surface
         # q * n_local + c * rows + r of the batch
-        iv_all = torch.empty((chunks, world, rows, N_MATURITIES, N_STRIKES), dtype=torch.float64, device=device)
+        iv_all = torch.empty((chunks, world, rows, N_MATURITIES, N_STRIKES) if gather_vols else (0,),
+                             dtype=torch.float64, device=device)
         flags_all = torch.empty((chunks, world, rows, 4), dtype=torch.int32, device=device)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * chunks + 1)] for _ in range(args.steps)]
 
     in_flight = [[] for _ in range(nbuf)]      # collectives still reading each pair of local buffers
     counter = [0]
+    steps_on_buffer = [0] * nbuf
 
     def step(events=None):
         b = counter[0] % nbuf
         counter[0] += 1
+        steps_on_buffer[b] += 1
         iv, flags_local = iv_bufs[b], flags_bufs[b]
         for w in in_flight[b]:                 # the step before last must have left these buffers
             w.wait()
@@ -325,10 +376,11 @@ def main():
                 # while the next chunk's kernels are enqueued behind them on ours
                 pending.append(dist.all_gather_into_tensor(flags_all[c].view(world * rows, 4), flags_local[sl],
                                                            async_op=True))
-                pending.append(dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES),
-                                                           iv[sl], async_op=True))
+                if gather_vols:
+                    pending.append(dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES),
+                                                               iv[sl], async_op=True))
             elif gather:
-                for dst, src in ((flags_all[c], flags_local[sl]), (iv_all[c], iv[sl])):
+                for dst, src in ((flags_all[c], flags_local[sl]),) + (((iv_all[c], iv[sl]),) if gather_vols else ()):
                     host = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype)
                     dist.all_gather_into_tensor(host, src.cpu())
                     dst.copy_(host.view(dst.shape))
@@ -369,12 +421,15 @@ def main():
         for c in range(chunks):
             sl = slice(c * rows, (c + 1) * rows)
             dist.all_gather_into_tensor(flags_all[c].view(world * rows, 4), flags_local[sl])
-            dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES), iv[sl])
+            if gather_vols:
+                dist.all_gather_into_tensor(iv_all[c].view(world * rows, N_MATURITIES, N_STRIKES), iv[sl])
         fence()
-        final_gather = {"what": "all-gather of implied vols and flag words, alone; inside a step it overlaps the "
-                                "next chunk's kernels and is part of `value`",
-                        "bytes_per_rank": iv.numel() * 8 + flags_local.numel() * 4,
-                        "ms": (time.perf_counter() - tg) * 1e3}
+        final_gather = {"what": ("all-gather of implied vols and flag words" if gather_vols else
+                                 "all-gather of the flag words (vols stay sharded)") +
+                                ", alone; inside a step it overlaps the next chunk's kernels and is part of `value`",
+                        "bytes_per_rank": (iv.numel() * 8 if gather_vols else 0) + flags_local.numel() * 4,
+                        "ms": (time.perf_counter() - tg) * 1e3,
+                        "steps_on_each_buffer_pair": list(steps_on_buffer)}
     elif gather:
         final_gather = {"what": "gloo rehearsal: gathers go through host memory, not timed separately"}
 
@@ -388,32 +443,51 @@ def main():
                 np.save(args.dump, flags_all.permute(1, 0, 2, 3).reshape(-1, 4).cpu().numpy())
             else:
                 np.save(args.dump, fl)
+        # Counter-derived figures come from the committed summary of a rocprofv3 --pmc run of this same
+        # command (tools/profile_round.sh); they are quoted only while the kernel sources still have
+        # the fingerprint that summary was measured on, and never silently otherwise.
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
+        sha = kernel_sources_sha()
+        fresh = bool(pmc) and pmc.get("kernel_sources_sha16") == sha
         per_launch = pmc.get("surfaces_per_launch")
+        source = (f"profiles/pmc_traffic.json@{sha} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if fresh
+                  else "none: the kernel sources changed since profiles/pmc_traffic.json was measured"
+                  if pmc else "none: no profiles/pmc_traffic.json")
 
-        def traffic(key):
+        def counters(kernel):
             # measured HBM bytes per launch, scaled to this run's surfaces per launch (traffic is
-            # proportional to the rows a launch processes)
-            v = pmc.get(key)
-            return None if not v or not per_launch else v * n_local / per_launch
+            # proportional to the rows a launch processes), and the share of issue slots in use
+            v = pmc.get(kernel + "_hbm_bytes_per_launch") if fresh else None
+            return {"traffic": None if not v or not per_launch else v * rows / per_launch,
+                    "traffic_source": source,
+                    "issue_slots_busy": pmc.get(kernel + "_issue_slots_busy") if fresh else None}
 
-        def roof(name, flops, seconds, pipe, traffic_key):
-            achieved = flops * n_local / seconds / 1e12
-            return {"bound": "mfma", "pipe": pipe, "kernel": name, "achieved": achieved,
-                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                    "traffic": traffic(traffic_key), "flops_per_surface": flops,
-                    "kernel_ms_per_step": seconds * 1e3, "launches_per_step": chunks,
-                    "surfaces_per_launch": rows}
-        r_price = roof("price_kernel", pricing_flops(N_MATURITIES, N_STRIKES), k_price,
-                       "FP64 vector + v_mfma_f64 (same 78.6 TFLOP/s peak)", "price_kernel_hbm_bytes_per_launch")
-        r_iv = roof("iv_fast_kernel", iv_checks_flops(N_MATURITIES, N_STRIKES), k_iv,
-                    "FP64 vector (no matrix work in this kernel); FLOPs by the contract's count of 12 "
-                    "root-finder iterations per point, the kernel needs 2", "iv_fast_kernel_hbm_bytes_per_launch")
+        common = {"launches_per_step": chunks, "surfaces_per_launch": rows}
+        fl_price = pricing_flops(N_MATURITIES, N_STRIKES)
+        tf_price = fl_price * n_local / k_price / 1e12
+        r_price = {"bound": "mfma", "kernel": "price_kernel",
+                   "pipe": "FP64 datapath: vector instructions and v_mfma_f64_16x16x4 share it and the same "
+                           "78.6 TFLOP/s peak; FLOPs by the contract's count (288 characteristic-function "
+                           "evaluations per maturity at 400, 1152 per option for the strike contraction)",
+                   "achieved": tf_price, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": tf_price / FP64_VECTOR_PEAK_TFLOPS, **counters("price_kernel"),
+                   "flops_per_surface": fl_price, "kernel_ms_per_step": k_price * 1e3, **common}
+        by_iv = iv_checks_bytes(N_MATURITIES, N_STRIKES)
+        gb_iv = by_iv * n_local / k_iv / 1e9
+        r_iv = {"bound": "hbm", "kernel": "iv_fast_kernel",
+                "pipe": "reads every price ratio once, writes every vol once; limited by FP64 vector instruction "
+                        "issue (see issue_slots_busy), not by HBM",
+                "achieved": gb_iv, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb_iv / HBM_PEAK_GBPS,
+                **counters("iv_fast_kernel"), "bytes_per_surface": by_iv, "kernel_ms_per_step": k_iv * 1e3, **common,
+                # the contract prices this stage at the reference's 12 root-finder iterations per point; the
+                # kernel needs one or two, so this is a rate of reference-equivalent work, not of executed FLOPs
+                "reference_equivalent_tflops": iv_checks_flops(N_MATURITIES, N_STRIKES) * n_local / k_iv / 1e12}
         dominant, other = (r_price, r_iv) if k_price >= k_iv else (r_iv, r_price)
+        what = {"all": "vols + flags", "flags": "flag words only (vols stay sharded)"}.get(mode, "")
         out = {
             "metric": "arb-checked IV surfaces/sec", "value": value, "unit": "surfaces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -426,18 +500,56 @@ def main():
                        "surfaces_per_step": total, "surfaces_per_gpu_per_step": n_local, "strikes": N_STRIKES,
                        "maturities": N_MATURITIES, "spot": SPOT, "r": R, "q": Q,
                        "parallelism": f"rows sharded over {world} rank(s)" +
-                                      (f", vols + flags all-gathered per {rows}-row chunk, overlapped" if gather else
+                                      (f", {what} all-gathered per {rows}-row chunk, overlapped" if gather else
                                        ", no collective")},
             "roofline": dominant,
             "roofline_other_kernel": other,
             # the same step without anything but rank 0's two kernels (events on the launch stream): what
             # `value` would be if the exchange were free
             "kernels_only": {"ms_per_step": (k_price + k_iv) * 1e3, "value": total / (k_price + k_iv)},
-            "whole_path_tflops": surface_flops(N_MATURITIES, N_STRIKES) * value / 1e12,
             "check": {"valid_surfaces_frac": float(np.mean((fl[:, 3] & 4) != 0)),
                       "arbitrage_free_frac": float(np.mean((fl[:, 3] & 1) != 0)),
                       "success_frac": float(np.mean((fl[:, 3] & 8) != 0))},
         }
+        if world > 1 and gather:
+            # What the exchange costs at link rate: every rank receives each peer's share over the one
+            # xGMI link between the two, all links in parallel.  Kernels and exchange overlap, so a step
+            # cannot be shorter than the longer of the two.
+            per_link = ((N_MATURITIES * N_STRIKES * 8 if gather_vols else 0) + 16) * n_local
+            ms_link = per_link / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3
+            out["xgmi_bound"] = {"bytes_per_link_per_step": per_link,
+                                 "link_GBps_per_direction": XGMI_LINK_GBPS_PER_DIRECTION,
+                                 "exchange_ms_per_step_at_link_rate": ms_link,
+                                 "value_at_link_rate": total / (max(ms_link, (k_price + k_iv) * 1e3) * 1e-3),
+                                 "note": "analytic; compare `value` with value_at_link_rate, and "
+                                         "`kernels_only` for the arithmetic alone"}
+        if world == 1 and not gather and not args.no_general_lattice:
+            # The headline lattice qualifies for both pricing shortcuts (half-strike contraction, stepped
+            # exponential).  The same batch on a lattice that qualifies for neither, outside the timing:
+            glm, gtau = general_lattice()
+            ggrid = afiv.Grid(glm, gtau, R, Q, device=device)
+            ge = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            reps = 2
+            for i in range(reps + 1):
+                if i == 1:
+                    ge[0].record()
+                ggrid.price(params, out=ratio)
+                if i == reps:
+                    ge[1].record()
+                ggrid.implied_vol_checked(ratio, SPOT, "A", iv_out=iv, flags_out=flags_local)
+            ge[2].record()
+            torch.cuda.synchronize()
+            # events 0 -> 2 span `reps` whole passes; 1 -> 2 the last implied-vol launch alone
+            g_iv = ge[1].elapsed_time(ge[2]) * 1e-3
+            g_all = ge[0].elapsed_time(ge[2]) * 1e-3 / reps
+            g_price = g_all - g_iv
+            out["general_lattice"] = {
+                "workload": f"the same {n_local} parameter sets on 50 unevenly spaced strikes x 20 irregular "
+                            "whole-day maturities: full-strike contraction, every exponential evaluated "
+                            "directly (traits: %s)" % json.dumps(ggrid.traits),
+                "ms_per_step": g_all * 1e3, "value": n_local / g_all, "price_ms": g_price * 1e3,
+                "iv_checks_ms": g_iv * 1e3,
+                "pricing_frac_of_fp64_peak": fl_price * n_local / g_price / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
         if final_gather is not None:
             out["final_gather"] = final_gather
         if not args.no_cpu_baseline and world == 1:

@@ -59,7 +59,8 @@ enum {
 /* Limits of this build. */
 #define AFIV_MAX_STRIKES 64      /* strikes per grid */
 #define AFIV_MAX_MATURITIES 64   /* maturities per grid */
-#define AFIV_MAX_ENSEMBLE 16384  /* surfaces per afiv_ensemble_stats call (one LDS-resident column) */
+#define AFIV_ENSEMBLE_ONE_SWEEP 16384  /* afiv_ensemble_stats: up to this many surfaces a column is sorted in LDS
+                                        * after one sweep; larger ensembles take three or four sweeps */
 #define AFIV_STATIC_SCRATCH_DOUBLES (4 * 1024 * 1024)   /* afiv_surface_static: N * nT * nK at most (32 MiB) */
 
 typedef struct afiv_grid afiv_grid;
@@ -84,10 +85,13 @@ int afiv_grid_destroy(afiv_grid *g);
 /* Which of the pricing kernel's shortcuts the lattice qualifies for (no counterpart in the
  * reference; for tests and for callers who want to know why one grid prices faster than another).
  * half_strike = 1: the strikes are symmetric about their midpoint (any linspace(a, b, n), n >= 4),
- * so half of them carry the matrix work.  stepped = 0, 1, 2: whole-day maturities a constant
+ * so half of them carry the matrix work.  stepped = 0, 1, 2, 3: whole-day maturities a constant
  * number of days apart (1), or a base step plus 0..3 days (2), advance exp(-d T) by complex
  * multiplications instead of an exp and a sincos per maturity; with trunc_days = 0, evenly spaced
- * year fractions (a linspace) do the same (1); 0: neither.  4 to 32 maturities either way.
+ * year fractions (a linspace) do the same (1); 3: whole-day maturities of which at least a quarter
+ * are sums of two earlier ones (the reference's own 30, 60, 91, 182, 273, 365, 547, 730 days), whose
+ * exponentials follow from those by one complex product; 0: none of these.  Modes 1 and 2 take 4 to
+ * 32 maturities.
  * Either pointer may be NULL.  Results do not depend on these beyond rounding. */
 int afiv_grid_traits(const afiv_grid *g, int *half_strike, int *stepped);
 
@@ -225,7 +229,8 @@ int afiv_density_wasserstein(const afiv_grid *g, const double *model_ratio, int6
  * iv: device [N,points] with points = nT*nK; select: NULL (use every surface) or device [N]
  * bytes, nonzero = use (the reference keeps the surfaces whose success flag is set, :466-467);
  * stats_out: device [4,points] = mean, median, 5th, 95th percentile; a grid point without any
- * non-NaN value gives NaN.  1 <= N <= AFIV_MAX_ENSEMBLE, points >= 1.  Needs no grid object;
+ * non-NaN value gives NaN.  1 <= N <= 2^31, points >= 1; no scratch memory whatever N is (large
+ * ensembles are read several times instead: see AFIV_ENSEMBLE_ONE_SWEEP).  Needs no grid object;
  * runs on the current device. */
 int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int64_t points,
                         double *stats_out, void *stream);
@@ -233,12 +238,15 @@ int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int6
 /* ---- diagnostics: the kernels' own FP64 elementary functions, element-wise, so that unit tests
  * can check them against high-precision references.  No counterpart in the reference (which
  * calls libm / SciPy).  x, y, out0, out1: device [n]; y only for AFIV_MATH_ATAN2 (atan2(x, y));
- * out1 only for AFIV_MATH_SINCOS (out0 = sin, out1 = cos), AFIV_MATH_EXPM1 and AFIV_MATH_COSM1; may be NULL. */
+ * out1 only for AFIV_MATH_SINCOS (out0 = sin, out1 = cos), AFIV_MATH_EXPM1, AFIV_MATH_COSM1
+ * and AFIV_MATH_EXPM1_TAB; may be NULL. */
 enum {
     AFIV_MATH_EXP = 0, AFIV_MATH_SINCOS = 1, AFIV_MATH_LOG1P = 2, AFIV_MATH_ATAN2 = 3,
     AFIV_MATH_RCP = 4, AFIV_MATH_NDTR = 5,
     AFIV_MATH_EXPM1 = 6,  /* out0 = exp(x) - 1, out1 = exp(x) */
-    AFIV_MATH_COSM1 = 7   /* out0 = cos(x) - 1, out1 = cos(x) */
+    AFIV_MATH_COSM1 = 7,  /* out0 = cos(x) - 1, out1 = cos(x) */
+    AFIV_MATH_EXP_TAB = 8,   /* the pricing kernel's table-driven exponential */
+    AFIV_MATH_EXPM1_TAB = 9  /* its exp(x) - 1 companion: out0 = exp(x) - 1, out1 = exp(x) */
 };
 int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,
                     void *stream);

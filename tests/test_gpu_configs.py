@@ -476,3 +476,45 @@ def test_config3_full_size_one_million_surfaces(afiv):
                           oracle.arb_check(iv[tail].cpu().numpy(), got, logm, tau, SPOT, R, Q, "A"))
     del ratio, iv, flags
     torch.cuda.empty_cache()
+
+
+def test_config3_census_of_fused_flags_at_headline_scale(afiv):
+    """The headline workload itself (bench.py's 1 048 576 distinct synthetic parameter sets x 20 x 50):
+    the flag words of the fused forward-form kernel -- which takes a landed vol's target price for its
+    re-priced value -- against (i) afiv_arb_check run on the kernel's own vols and ratios and (ii) the
+    flag words of the kernel that walks brentq's path.  Every surface must agree with (i).  Against (ii)
+    the vols differ by up to brentq's xtol, i.e. the re-priced values by vega x 2.5e-7 (3e-3 at this
+    spot): a surface may differ only where one of ITS OWN price differences sits that close to the
+    1e-6 threshold, which is checked from the stand-alone kernel's violation mask margins."""
+    import bench
+    logm, tau = bench.grids()
+    grid = afiv.Grid(logm, tau, R, Q)
+    n, chunk = bench.TOTAL_SURFACES, 262144
+    free, _total = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs 12 GB of free device memory")
+    params = bench.synthetic_params(n, 3, "cuda")
+    mism_own = mism_brent = nan_mask_diff = 0
+    far_brent = 0
+    for lo in range(0, n, chunk):
+        ratio = grid.price(params[lo:lo + chunk])
+        iv, fl = grid.implied_vol_checked(ratio, bench.SPOT, "A")
+        fl_own = grid.arb_check(iv, ratio, bench.SPOT, "A")
+        iv_b, fl_b = grid.implied_vol_checked(ratio, bench.SPOT, "A_BRENT")
+        mism_own += int((fl != fl_own).any(dim=1).sum())
+        d = (fl != fl_b).any(dim=1)
+        mism_brent += int(d.sum())
+        nan_mask_diff += int((torch.isnan(iv) != torch.isnan(iv_b)).sum())
+        if bool(d.any()):
+            # a differing surface must hold vols that differ enough to move a re-priced value across
+            # a threshold: not a single one may differ where the two kernels' vols agree to 1e-9
+            rows = d.nonzero().flatten()
+            gap = torch.nan_to_num((iv[rows] - iv_b[rows]).abs(), nan=0.0).amax(dim=(1, 2))
+            far_brent += int((gap < 1e-9).sum())
+        del ratio, iv, iv_b
+    print(f"census over {n} surfaces: {mism_own} flag words differ from afiv_arb_check on the kernel's own vols, "
+          f"{mism_brent} from the Brent-path kernel's, {nan_mask_diff} NaN-mask differences")
+    assert mism_own == 0
+    assert nan_mask_diff == 0
+    assert far_brent == 0
+    assert mism_brent <= n // 100000          # a handful at most: brentq's own stopping distance

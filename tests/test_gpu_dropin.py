@@ -2,6 +2,7 @@
 heston_model_ql / cvae_model / generate_iv_surface_by_date / generate_regime_surfaces, checked
 against the oracle and the golden vectors."""
 import importlib
+import os
 import sys
 
 import numpy as np
@@ -179,6 +180,35 @@ def test_generate_iv_surface_signature_and_values(mods):
     ivs, oks = G.generate_iv_surfaces(np.tile(params, (5, 1)), G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)
     assert ivs.shape == (5, 8, 21) and oks.shape == (5,)
     assert np.array_equal(np.nan_to_num(ivs[3], nan=-1), np.nan_to_num(iv, nan=-1))
+
+
+def test_statistics_on_the_device_over_the_all_dates_batch(mods, golden_dir):
+    """The all-dates batch (500 conditioning rows x 100 samples = 50 000 surfaces) through the
+    on-device path: vols and success bits stay CUDA tensors, the success bits are the statistics'
+    selection mask, and the four surfaces equal NumPy's own nanmean / nanmedian / nanpercentile
+    (generate_iv_surface_by_date.py:474-478) over the successful surfaces bit for bit."""
+    G = mods["generate_iv_surface_by_date"]
+    # decoded-parameter-like rows: the sampler of the synthetic configuration
+    import bench
+    params = bench.synthetic_params(50000, 11, "cuda")
+    iv, ok = G.generate_iv_surfaces(params, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0, on_device=True)
+    assert iv.is_cuda and ok.is_cuda and iv.shape == (50000, 8, 21) and ok.dtype == torch.bool
+    iv_h, ok_h = G.generate_iv_surfaces(params, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)
+    assert np.array_equal(ok.cpu().numpy(), ok_h)
+    assert np.array_equal(np.nan_to_num(iv.cpu().numpy(), nan=-1.0), np.nan_to_num(iv_h, nan=-1.0))
+    got = G.ensemble_statistics(iv, ok)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        valid = iv_h[ok_h]
+        ref = (np.nanmean(valid, axis=0), np.nanmedian(valid, axis=0),
+               np.nanpercentile(valid, 5, axis=0), np.nanpercentile(valid, 95, axis=0))
+    assert 1000 < len(valid) < 50000
+    for g, r in zip(got, ref):
+        assert np.array_equal(np.nan_to_num(g, nan=-1.0), np.nan_to_num(r, nan=-1.0))
+    # the host form of the same call (the reference's own stacking of valid surfaces)
+    for g, r in zip(G.ensemble_statistics(valid), ref):
+        assert np.array_equal(np.nan_to_num(g, nan=-1.0), np.nan_to_num(r, nan=-1.0))
 
 
 def test_older_twin_module_resolves_to_same_function(mods):

@@ -13,7 +13,7 @@ def run(afiv, op, x, y=None):
     xd = torch.tensor(x, dtype=torch.float64, device="cuda")
     yd = None if y is None else torch.tensor(y, dtype=torch.float64, device="cuda")
     out = afiv.debug_math(op, xd, yd)
-    if op in ("sincos", "expm1", "cosm1"):
+    if op in ("sincos", "expm1", "cosm1", "expm1_tab"):
         return out[0].cpu().numpy(), out[1].cpu().numpy()
     return out.cpu().numpy()
 
@@ -22,9 +22,19 @@ def relerr(got, ref):
     return np.array([abs(float((mp.mpf(float(g)) - r) / r)) if r != 0 else abs(float(g)) for g, r in zip(got, ref)])
 
 
-def test_exp(afiv):
+@pytest.mark.parametrize("which", ["exp", "exp_tab"])
+def test_exp(afiv, which):
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-700, 700, 3000), rng.uniform(-2, 2, 3000), [0.0, -745.0, 709.0, 1e-300]])
+    if which == "exp_tab":                 # no clamp in the table form: finite arguments only
+        got = run(afiv, which, x)
+        ref = [mp.exp(mp.mpf(float(v))) for v in x]
+        normal = np.array([float(r) > 1e-300 for r in ref])
+        assert relerr(got[normal], [r for r, k in zip(ref, normal) if k]).max() <= 3 * EPS
+        assert np.all(got[~normal] < 1e-300)
+        edge = run(afiv, which, np.array([-1e6, -800.0, 800.0, np.nan]))
+        assert edge[0] == 0 and edge[1] == 0 and np.isinf(edge[2]) and np.isnan(edge[3])
+        return
     got = run(afiv, "exp", x)
     ref = [mp.exp(mp.mpf(float(v))) for v in x]
     normal = np.array([float(r) > 1e-300 for r in ref])        # subnormal results: absolute only
@@ -33,6 +43,20 @@ def test_exp(afiv):
     edge = run(afiv, "exp", np.array([-1e300, -800.0, 800.0, np.inf, -np.inf, np.nan]))
     assert edge[0] == 0 and edge[1] == 0 and np.isinf(edge[2]) and np.isinf(edge[3]) and edge[4] == 0
     assert np.isnan(edge[5])
+
+
+def test_table_expm1_keeps_relative_accuracy_everywhere(afiv):
+    """The table-driven exp(x) - 1 of the pricing kernel: 2^m T_j - 1 is exact where it cancels, so
+    the relative accuracy holds at every argument, the bin edges around zero included."""
+    rng = np.random.default_rng(17)
+    edges = np.log(2) / 256 * np.array([1, -1, 0.999, -0.999, 1.001, -1.001, 3, -3, 255, -255, 257, -257])
+    x = np.concatenate([rng.uniform(-30, 30, 2000), rng.uniform(-0.4, 0.4, 3000), rng.uniform(-0.02, 0.02, 3000),
+                        10.0 ** rng.uniform(-300, -1, 2000) * rng.choice([-1.0, 1.0], 2000), edges])
+    em1, e = run(afiv, "expm1_tab", x)
+    assert relerr(em1, [mp.expm1(mp.mpf(float(v))) for v in x]).max() <= 4 * EPS
+    assert relerr(e, [mp.exp(mp.mpf(float(v))) for v in x]).max() <= 3 * EPS
+    em1, e = run(afiv, "expm1_tab", np.array([-800.0, -1e6]))
+    assert np.all(em1 == -1.0) and np.all(e == 0.0)
 
 
 def test_expm1_and_cosm1_keep_relative_accuracy_near_zero(afiv):

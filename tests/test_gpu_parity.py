@@ -470,11 +470,39 @@ def test_ensemble_statistics_select_and_limits(afiv):
     got = afiv.ensemble_stats(dev(s), torch.as_tensor(keep).cuda()).cpu().numpy()
     ref = np.stack(oracle.ensemble_stats(s[keep]))
     assert np.array_equal(got, ref)
-    with pytest.raises(ValueError):
-        afiv.ensemble_stats(torch.zeros((afiv.MAX_ENSEMBLE + 1, 2, 2), dtype=torch.float64, device="cuda"))
-    big = 0.2 + 0.01 * rng.standard_normal((afiv.MAX_ENSEMBLE, 2, 3))
+    big = 0.2 + 0.01 * rng.standard_normal((afiv.ENSEMBLE_ONE_SWEEP, 2, 3))
     got = afiv.ensemble_stats(dev(big)).cpu().numpy()
     assert np.array_equal(got, np.stack(oracle.ensemble_stats(big)))
+
+
+@pytest.mark.parametrize("n,shape", [(16385, (8, 21)), (50000, (8, 21)), (50001, (3, 5)), (300000, (2, 9)),
+                                     (1 << 20, (1, 8))])
+def test_large_ensembles_equal_numpy_bit_for_bit(afiv, n, shape):
+    """Ensembles beyond one LDS-resident column (the 50 000 surfaces of the all-dates batch, a
+    million synthetic ones) take several sweeps over the stack instead of scratch memory: the same
+    four statistics as NumPy, bit for bit, with NaNs, a success mask, columns of equal values,
+    heavy ties, values of both signs and a column spanning many binades."""
+    rng = np.random.default_rng(n)
+    s = 0.2 + 0.05 * rng.standard_normal((n,) + shape)
+    s[rng.random(s.shape) < 0.1] = np.nan
+    s[:, 0, 0] = np.nan                                           # no value at all
+    s[:, 0, 1] = 0.25                                             # all equal
+    s[:, 0, 2] = np.round(s[:, 0, 2], 2)                          # a few distinct values, heavy ties
+    s[:, 0, 3] = rng.standard_normal(n) * 10.0 ** rng.integers(-12, 3, n)     # both signs, many binades
+    s[:, 0, 4] = np.nan
+    s[n // 3, 0, 4] = 0.5                                         # a single value
+    keep = rng.random(n) < 0.8
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_all = np.stack(oracle.ensemble_stats(s))
+        ref_sel = np.stack(oracle.ensemble_stats(s[keep]))
+    d = dev(s)
+    for got, ref in ((afiv.ensemble_stats(d).cpu().numpy(), ref_all),
+                     (afiv.ensemble_stats(d, torch.as_tensor(keep).cuda()).cpu().numpy(), ref_sel)):
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(ref, nan=-1.0)), \
+            f"max difference {np.nanmax(np.abs(got - ref)):.3g}"
 
 
 def test_price_against_50_digit_quadrature_at_small_vol_of_vol(afiv, golden_dir):
@@ -519,7 +547,8 @@ def test_price_against_60_digit_quadrature_at_the_corners_and_on_the_series_bran
     ([30, 67, 104, 141, 177, 214, 250, 288, 325], 2),      # 36..38 days: base step plus one-day factors
     ([10, 13, 16, 20, 23, 26, 29, 33], 2),                 # base 3 days, up to 1 extra
     ([30, 67, 104, 140, 177, 214, 251, 287, 324], 2),      # mostly 37 days, some 36: base 37 minus one-day factors
-    ([30, 60, 91, 182, 273, 365, 547, 730], 0),            # irregular: every maturity evaluated directly
+    ([30, 60, 91, 182, 273, 365, 547, 730], 3),            # irregular, but five of the eight are sums of earlier ones
+    ([30, 61, 93, 187, 277, 369, 551, 733], 0),            # irregular: every maturity evaluated directly
 ])
 def test_price_regular_and_irregular_term_structures(afiv, days, stepped):
     """Whole-day year fractions take the stepped evaluation of exp(-d T) when the increments allow
@@ -552,6 +581,49 @@ def test_stepped_exponential_agrees_with_direct_evaluation(afiv):
         sub = afiv.Grid(logm, tau[lo:lo + 3], R, Q).price(p).cpu().numpy()
         worst = max(worst, float(np.abs(sub - full[:, lo:lo + 3]).max()))
     assert worst <= 2e-13, worst
+
+
+def test_sum_of_maturities_program_agrees_with_direct_evaluation(afiv):
+    """The reference's own term structure (30, 60, 91, 182, 273, 365, 547, 730 days) holds maturities
+    that are sums of earlier ones: the kernel forms their 1 - exp(-d T) from two earlier values
+    (traits: stepped == 3).  Single-maturity grids are always evaluated directly; the two agree to
+    rounding, and the program-driven values meet the oracle's bound."""
+    grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
+    assert grid.traits["stepped"] == 3
+    p = sample_params(3000, 47)
+    full = grid.price(dev(p)).cpu().numpy()
+    ref = oracle.price_ratio_grid(p[:256], LOGM_GRID, T_GRID, R, Q)
+    assert np.all(np.abs(full[:256] - ref) <= price_tol(ref, p[:256]))
+    worst = 0.0
+    for t in range(len(T_GRID)):
+        one = afiv.Grid(LOGM_GRID, T_GRID[t:t + 1], R, Q)
+        assert one.traits["stepped"] == 0
+        worst = max(worst, float(np.abs(one.price(dev(p)).cpu().numpy()[:, 0] - full[:, t]).max()))
+    assert worst <= 2e-13, worst
+    # other shapes of the same idea: unsorted, repeated and doubling maturities; a lattice without
+    # any such relation is left to the direct path
+    for days, want in (([7, 14, 30, 60], 3), ([60, 30, 90, 120, 240], 3), ([30, 30, 60, 60, 120], 3),
+                       ([11, 23, 47, 95, 191, 383], 0)):
+        tau = (np.array(days) + 0.25) / 365.0
+        g2 = afiv.Grid(LOGM_GRID, tau, R, Q)
+        assert g2.traits["stepped"] == want, days
+        got = g2.price(dev(p[:512])).cpu().numpy()
+        for t in range(len(days)):
+            one = afiv.Grid(LOGM_GRID, tau[t:t + 1], R, Q).price(dev(p[:512])).cpu().numpy()[:, 0]
+            assert float(np.abs(one - got[:, t]).max()) <= 2e-13, (days, t)
+
+
+def test_small_batches_replay_the_program_without_changing_a_bit(afiv):
+    """A small batch on the reference's term structure splits its maturities over several workgroups,
+    each of which replays the earlier steps of the sum-of-maturities program first: the rows equal
+    those of a large call bit for bit."""
+    grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
+    assert grid.traits["stepped"] == 3
+    p = dev(sample_params(3000, 23))
+    big = grid.price(p)
+    for n in (1, 6, 7, 8, 100, 700, 896, 903):
+        small = grid.price(p[:n].contiguous())
+        assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), n
 
 
 def test_stepped_exponential_on_evenly_spaced_exact_year_fractions(afiv):

@@ -5,6 +5,10 @@ binary64; binary64 models of the table-driven functions are checked against mpma
 
   exp r  = sum_{k<=13} r^k / k!      |r| <= ln(2)/2  (plain Taylor: remainder 4e-18)
 
+Table-driven exp (afivm::exp_tab_f64): x = (128 m + j) ln(2)/128 + r, |r| <= ln(2)/256, table of
+2^(j/128) as (hi, lo), exp r - 1 by the Taylor polynomial to r^5 (remainder r^6/720 = 5e-19, i.e.
+2e-16 of exp r - 1 itself at the interval's ends, where exp x - 1 is returned as that polynomial).
+
 Table-driven sincos (afivm::sincos_tab_f64): x = j pi/32 + r, |r| <= pi/64, table of
 (sin, cos)(j pi/32), j < 64, correctly rounded; sin r and cos r - 1 by Taylor polynomials
 (remainders r^9/9! = 5e-18 and r^10/10! = 2e-20).
@@ -121,6 +125,47 @@ def atan_tab_model(t, rows):
     return p
 
 
+def exp_table():
+    """(hi, lo) of 2^(j/128), j < 128: hi the nearest double, lo the remainder."""
+    rows = []
+    for j in range(128):
+        v = mp.mpf(2) ** (mp.mpf(j) / 128)
+        hi = float(v)
+        rows.append((hi, float(v - mp.mpf(hi))))
+    return rows
+
+
+def ln2_over_128_split():
+    """ln(2)/128 = hi + lo with hi carrying 32 significant bits, so that k hi is exact for |k| < 2^21."""
+    import struct
+    v = mp.log(2) / 128
+    bits = struct.unpack("<Q", struct.pack("<d", float(v)))[0]
+    hi = struct.unpack("<d", struct.pack("<Q", bits & ~((1 << 21) - 1)))[0]
+    return hi, float(v - mp.mpf(hi))
+
+
+def exp_tab_model(x, rows, hi, lo, inv):
+    """binary64 model of afivm::exp_tab_f64 / exp_expm1_tab_f64: returns (exp x, exp x - 1)."""
+    def fma(a, b, c):
+        return float(mp.mpf(a) * mp.mpf(b) + mp.mpf(c))
+    k = float(np.rint(x * inv))
+    r = fma(k, -hi, x)
+    r = fma(k, -lo, r)
+    ki = int(k)
+    j, m = ki & 127, ki >> 7
+    p = 1.0 / 120
+    for cf in (1.0 / 24, 1.0 / 6, 0.5):
+        p = fma(p, r, cf)
+    q = fma(p, r, 1.0)
+    w = q * r                                    # exp(r) - 1
+    th, tl = rows[j]
+    e = float(np.ldexp(fma(th, w, th), m))       # the plain exponential uses the high part only
+    v = fma(th, w, tl)
+    s = float(np.ldexp(1.0, m))
+    ts, vs = th * s, v * s
+    return e, ts + vs, (ts - 1.0) + vs
+
+
 def horner(c, z):
     acc = np.float64(c[-1])
     for v in c[-2::-1]:
@@ -157,9 +202,23 @@ def main():
     for t in np.concatenate([rng.uniform(0, 1, 8000), 10.0 ** rng.uniform(-15, -1, 1500), [1.0, 1.0 / 128, 3.0 / 128, 0.5]]):
         ref = mp.atan(mp.mpf(float(t)))
         worst["atan_tab"] = max(worst["atan_tab"], abs(float((mp.mpf(atan_tab_model(float(t), arows)) - ref) / ref)))
+    erows = exp_table()
+    e_hi, e_lo = ln2_over_128_split()
+    e_inv = float(128 / mp.log(2))
+    worst["exp_tab"] = worst["exp_tab2"] = worst["expm1_tab"] = 0
+    xs = np.concatenate([rng.uniform(-700, 700, 3000), rng.uniform(-2, 2, 4000), rng.uniform(-0.05, 0.05, 3000),
+                         10.0 ** rng.uniform(-300, -1, 1500), -(10.0 ** rng.uniform(-300, -1, 1500))])
+    for x in xs:
+        x = float(x)
+        e, e2, em1 = exp_tab_model(x, erows, e_hi, e_lo, e_inv)
+        ref = mp.exp(mp.mpf(x))
+        worst["exp_tab"] = max(worst["exp_tab"], abs(float((mp.mpf(e) - ref) / ref)))
+        worst["exp_tab2"] = max(worst["exp_tab2"], abs(float((mp.mpf(e2) - ref) / ref)))
+        refm = mp.expm1(mp.mpf(x))
+        worst["expm1_tab"] = max(worst["expm1_tab"], abs(float((mp.mpf(em1) - refm) / refm)))
     print("binary64 accuracy (relative):")
     for k, v in worst.items():
-        print(f"  {k:6s} {v:.3e}")
+        print(f"  {k:9s} {v:.3e}")
 
     out = os.path.join(root, "arbitrage-free-iv-surfaces-using-vae_amd", "csrc", "afiv_math_coeffs.inc")
     with open(out, "w") as fh:
@@ -177,6 +236,11 @@ def main():
         for name, v in (("AFIV_LN2_HI", l1), ("AFIV_LN2_LO", l2), ("AFIV_LOG2E", float(1 / ln2)),
                         ("AFIV_PI", float(mp.pi)), ("AFIV_PIO4", float(mp.pi / 4))):
             fh.write("#define %s %s\n" % (name, float(v).hex()))
+        # table-driven exp: ln(2)/128 in two pieces, 128/ln(2), (hi, lo) of 2^(j/128)
+        for name, v in (("AFIV_LN2O128_HI", e_hi), ("AFIV_LN2O128_LO", e_lo), ("AFIV_128_OVER_LN2", e_inv)):
+            fh.write("#define %s %s\n" % (name, float(v).hex()))
+        fh.write("#define AFIV_EXP_TAB_LIST \\\n")
+        fh.write(", \\\n".join("  %s, %s" % (a.hex(), b.hex()) for a, b in erows) + "\n")
         # table-driven sincos: pi/32 in two pieces, Taylor coefficients, (sin, cos)(j pi/32)
         pio32 = mp.pi / 32
         q1 = float(pio32)
