@@ -193,8 +193,9 @@ class Grid:
     def surface_static(self, params: torch.Tensor, spot: float, variant="A", *, iv_out: torch.Tensor,
                        flags_out: torch.Tensor):
         """``surface`` for callers that cannot allocate (see afiv_surface_static): outputs are the
-        caller's, the price ratios pass through a fixed array inside the library.  At most
-        ``STATIC_SCRATCH_DOUBLES // (nT * nK)`` surfaces per call; calls on one GPU must not overlap."""
+        caller's, the price ratios pass through a fixed array inside the library -- in pieces of
+        ``STATIC_SCRATCH_DOUBLES // (nT * nK)`` surfaces at most when the batch is larger; calls on
+        one GPU must not overlap."""
         p = self._params(params)
         n = p.shape[0]
         iv = self._lattice(iv_out, "iv_out")

@@ -66,8 +66,9 @@ const char *afiv_error_string(int code)
         case AFIV_E_HIP: return "HIP runtime call, kernel launch or host allocation failed";
         case AFIV_E_ARG: return "bad argument (enum value, or object used on a different device)";
         case AFIV_E_WORKSPACE: return "grid was created without the workspace this call needs";
-        case AFIV_E_SCRATCH: return "batch exceeds the static scratch of afiv_surface_static "
-                                    "(N * nT * nK must not exceed AFIV_STATIC_SCRATCH_DOUBLES)";
+        case AFIV_E_SCRATCH: return "batch exceeds what afiv_surface_static passes through its static scratch "
+                                    "in one call (AFIV_STATIC_MAX_PIECES pieces of AFIV_STATIC_SCRATCH_DOUBLES / "
+                                    "(nT * nK) surfaces)";
         default: return "unknown error";
     }
 }
@@ -421,13 +422,30 @@ int afiv_surface_static(const afiv_grid *g, const double *params, int64_t N, dou
     if (N == 0) return AFIV_OK;
     if (!params || !iv_out || !flags_out) return AFIV_E_NULL;
     const int64_t per = (int64_t)g->v.nT * g->v.nK;
-    if (N > (int64_t)AFIV_STATIC_SCRATCH_DOUBLES / per) return AFIV_E_SCRATCH;
+    // Batches beyond the array go through it in pieces, one pair of launches each.  A piece is a
+    // multiple of 7 x 256 surfaces where the array allows (the pricing kernel's workgroups take seven
+    // surfaces at a time and one workgroup fits a CU, so every CU gets the same share), and the
+    // pieces are evened out so that the last one is not a sliver.
+    const int64_t fit = (int64_t)AFIV_STATIC_SCRATCH_DOUBLES / per, wave = 7 * 256;
+    int64_t piece = fit >= wave ? fit / wave * wave : fit;
+    const int64_t pieces = (N + piece - 1) / piece;
+    if (pieces > AFIV_STATIC_MAX_PIECES) return AFIV_E_SCRATCH;
+    if (pieces > 1 && piece >= wave) {
+        const int64_t even = ((N + pieces - 1) / pieces + wave - 1) / wave * wave;
+        if (even < piece) piece = even;
+    }
     double *ratio = nullptr;
     if ((rc = scratch_for_current_device(&ratio))) return rc;
     hipStream_t s = as_stream(stream);
-    // every ratio the second kernel reads has been written by the first: nothing to clear
-    if ((rc = afiv_launch_price(g->v, params, N, ratio, s))) return rc;
-    return afiv_launch_surface_iv(g->v, ratio, N, spot, variant, iv_out, flags_out, s);
+    // Every ratio the second kernel reads has been written by the first: nothing to clear.  Stream
+    // order makes the reuse of the array by consecutive pieces safe.
+    for (int64_t off = 0; off < N; off += piece) {
+        const int64_t n = N - off < piece ? N - off : piece;
+        if ((rc = afiv_launch_price(g->v, params + 5 * off, n, ratio, s))) return rc;
+        if ((rc = afiv_launch_surface_iv(g->v, ratio, n, spot, variant, iv_out + off * per, flags_out + 4 * off, s)))
+            return rc;
+    }
+    return AFIV_OK;
 }
 
 int afiv_decoder_create(afiv_decoder **out, const afiv_decoder_weights *w)

@@ -31,7 +31,6 @@
 // of the epilogue are staged there too, because the epilogue runs between two workgroup barriers
 // where no other wave's work covers a global load.
 #include <algorithm>
-#include <cstdlib>
 
 #include "afiv_internal.h"
 #include "afiv_math.h"
@@ -78,17 +77,42 @@ __device__ __forceinline__ Cx crcp(Cx b)
     const double inv = afivm::rcp_f64(b.r * b.r + b.i * b.i);
     return {b.r * inv, -b.i * inv};
 }
+// sqrt(x) and 1/sqrt(x) for a positive normal x well inside the exponent range (sums of squares of
+// moderate numbers here): v_rsq_f64 and two Newton steps on the pair -- a dozen instructions where
+// the library's square root (scaling for subnormals, special values) and an IEEE division take
+// forty.  Both results to 1 ulp.
+__device__ __forceinline__ double sqrt_rsqrt(double x, double *rs)
+{
+    double y = __builtin_amdgcn_rsq(x);                   // ~ 2^-26 relative... refined below
+    double g = x * y;                                     // ~ sqrt(x)
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double e = __builtin_fma(-g, g, x);             // residual of the root
+    g = __builtin_fma(e, h, g);
+    *rs = 2.0 * h;
+    return g;
+}
+
 __device__ __forceinline__ Cx csqrt_principal(Cx z)
 {
-    const double m = sqrt(z.r * z.r + z.i * z.i);
+    double unused, rs;
+    const double m = sqrt_rsqrt(__builtin_fma(z.r, z.r, z.i * z.i), &unused);
+    // the larger of the two parts is sqrt((m + |Re z|)/2), never a difference of close numbers; the
+    // other is Im z / (2 x that): one reciprocal square root serves both
+    const double big = sqrt_rsqrt(0.5 * (m + fabs(z.r)), &rs);
+    const double small = 0.5 * fabs(z.i) * rs;
     Cx d;
     if (z.r >= 0.0) {
-        d.r = sqrt(0.5 * (m + z.r));
-        d.i = (d.r > 0.0) ? 0.5 * z.i / d.r : 0.0;
+        d.r = big;
+        d.i = copysign(small, z.i);
     } else {
-        const double t = sqrt(0.5 * (m - z.r));
-        d.r = 0.5 * fabs(z.i) / t;
-        d.i = copysign(t, z.i);
+        d.r = small;
+        d.i = copysign(big, z.i);
     }
     return d;
 }
@@ -360,8 +384,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                          rho = params[5 * s + 3], v0 = params[5 * s + 4];
             m.sigma2 = sigma * sigma;
             m.main_branch = sigma > 1e-5;
-            m.c1 = m.main_branch ? v0 / m.sigma2 : v0;
-            m.c2 = m.main_branch ? (kappa * theta) / m.sigma2 : kappa * theta;
+            // (one reciprocal for both quotients: an IEEE division is twenty instructions)
+            const double inv_s2 = m.main_branch ? afivm::rcp_f64(m.sigma2) : 1.0;
+            m.c1 = v0 * inv_s2;
+            m.c2 = (kappa * theta) * inv_s2;
             st0 = cf_setup<0>(kappa, sigma, rho, m, phi);
             st1 = cf_setup<1>(kappa, sigma, rho, m, phi);
             if (m.main_branch) {
@@ -632,9 +658,8 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     // drains the pipeline (the last tile's contraction and epilogue), and a batch ends when the
     // last workgroup does: with fewer than 64 chunks per CU both are worth more than the dynamic
     // balancing of many short workgroups, so each CU gets ONE workgroup and an equal share of the
-    // chunks (50 000 surfaces on 8 x 21: 1.09 -> ms); large batches keep eight rounds of workgroups.
-    int64_t blocks = chunks < 256 * 64 ? std::min<int64_t>(chunks, 256) : 256 * 8;
-    if (const char *e = getenv("AFIV_PRICE_BLOCKS")) blocks = std::min<int64_t>(chunks, atoi(e));
+    // chunks (50 000 surfaces on 8 x 21: -3 %); large batches keep eight rounds of workgroups.
+    const int64_t blocks = chunks < 256 * 64 ? std::min<int64_t>(chunks, 256) : 256 * 8;
     // Fewer workgroups than CUs: a call's time is one workgroup's walk through its surfaces'
     // maturities, two per step.  Where maturities are evaluated independently (no stepped
     // exponential) that walk is split over several workgroups per chunk of surfaces.
