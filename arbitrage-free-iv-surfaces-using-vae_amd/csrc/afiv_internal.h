@@ -78,6 +78,9 @@ struct afiv_decoder {
 // current device, not on every launch: `raised` is the kernel's own table, one entry per device.
 #define AFIV_MAX_DEVICES 64
 #define AFIV_LDS_PER_CU (160 * 1024)      // gfx950
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "these kernels are written for gfx950: 160 KB of LDS per CU, v_mfma_f64_16x16x4_f64, 64-wide waves"
+#endif
 struct DynLdsLimit { std::atomic<size_t> bytes[AFIV_MAX_DEVICES]; };
 inline int afiv_ensure_dynamic_lds(const void *kernel, size_t bytes, DynLdsLimit &raised)
 {

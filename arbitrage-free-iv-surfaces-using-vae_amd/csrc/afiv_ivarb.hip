@@ -130,6 +130,8 @@ __global__ __launch_bounds__(ARB_THREADS) void arb_kernel(GridView g, const doub
 // taken from Brent's last objective value (objective + target, exact at a root), so the static
 // and calendar checks cost no further normal CDFs.  Vols go straight to global memory.
 struct MatRow { double tau, sqrt_tau, disc, F, sdq, fwd; };
+static_assert(sizeof(MatRow) % 16 == 0 && (ERFCX_LDS * sizeof(double)) % 16 == 0,
+              "the arrays behind the maturity rows in dynamic LDS are read as 16-byte pairs");
 
 template <int GT>
 __device__ __forceinline__ void group_sync()
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(THREADS) void surface_kernel(GridView g, const doub
                                                           int32_t *__restrict__ flags)
 {
     constexpr int NG = THREADS / GT;
-    extern __shared__ double dyn[];
+    extern __shared__ __align__(16) double dyn[];
     const int nT = g.nT, nK = g.nK, per = nT * nK;
     double *tab = dyn;                                   // ERFCX_LDS
     MatRow *mat = reinterpret_cast<MatRow *>(tab + ERFCX_LDS);                // [64]
@@ -520,7 +522,7 @@ size_t surface_lds_bytes(const GridView &g, int groups, int variant, bool fktab 
 
 size_t surface_static_lds(int groups) { return (size_t)groups * (AFIV_MAX_MATURITIES + 8) * sizeof(int); }
 
-constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr size_t LDS_PER_CU = AFIV_LDS_PER_CU;
 
 template <int VARIANT, bool CHECKS, int GT, int THREADS, bool FKTAB = true>
 int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
@@ -529,12 +531,10 @@ int launch_surface_kernel(const GridView &g, const double *ratio, int64_t N, dou
     constexpr int NG = THREADS / GT;
     const size_t lds = surface_lds_bytes(g, NG, VARIANT, FKTAB);
     if (lds + surface_static_lds(NG) > LDS_PER_CU) return AFIV_E_SHAPE;
-    if (lds > 48 * 1024) {
-        // raising the dynamic-LDS limit is a per-function attribute, not an allocation
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return AFIV_E_HIP;
-    }
+    static DynLdsLimit raised;
+    if (const int rc = afiv_ensure_dynamic_lds(
+            reinterpret_cast<const void *>(&surface_kernel<VARIANT, CHECKS, GT, THREADS, FKTAB>), lds, raised))
+        return rc;
     // few, long-lived workgroups: each one tabulates the bracket ends of the whole lattice first
     int64_t blocks = (N + NG - 1) / NG;
     const int64_t cap = GT == 64 ? 256 * 4 : 256 * 8;

@@ -123,7 +123,8 @@ void iv_fast_kernel(GridView g, const double *__restrict__ ratio, int64_t N, dou
     // per wave and maturity: negative-butterfly count, and whether the row holds a NaN / negative ratio
     __shared__ int fly_all[FAST_WAVES][AFIV_MAX_MATURITIES];
     __shared__ int skip_all[FAST_WAVES][AFIV_MAX_MATURITIES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: the surface index and its pointers stay scalar
     int *skip_t = skip_all[wave];
     int *fly_t = fly_all[wave];
 

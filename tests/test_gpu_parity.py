@@ -22,6 +22,8 @@ Tolerances (from the north-star statement, made well-posed):
   flags   bit-exact given identical IV / ratio inputs
   decode  float32, |d| <= 2e-5 * max(1, |x|) (summation order differs from torch's GEMM)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -98,6 +100,14 @@ def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002, sam
     assert d.size == 0 or d.max() <= 1e-6, f"max IV difference {d.max():.3g}"
     m2 = ~well & ~both_nan & ~mism
     d2 = np.abs(got - ref)
+    if os.environ.get("AFIV_IV_RULE_REPORT"):
+        import inspect
+        site = inspect.stack()[1]
+        with open(os.environ["AFIV_IV_RULE_REPORT"], "a") as fh:
+            fh.write(f"{os.path.basename(site.filename)}:{site.lineno} {site.function} same_path={same_path} "
+                     f"points={got.size} well={int(m.sum())} ill={int(m2.sum())} mism_ill={int(np.sum(mism))} "
+                     f"ill_beyond_1e-6={int(np.sum(m2 & (d2 > 1e-6)))} "
+                     f"ill_max={float(d2[m2].max()) if m2.any() else 0.0:.3g} well_max={float(d.max()) if d.size else 0.0:.3g}\n")
     if same_path:
         assert not m2.any() or d2[m2].max() <= 1e-4, f"ill-conditioned IV difference {d2[m2].max():.3g}"
     else:
