@@ -4,6 +4,8 @@ strikes, whole-day / irregular / unsorted / sub-day maturities, day truncation o
 of either sign, spots over five decades, both Black-Scholes forms, ragged batch sizes,
 benchmark-sampler parameters mixed with corner values.  ``run_case`` compares one trial with the
 CPU oracle by the rules of tests/test_gpu_parity.py."""
+import os
+
 import numpy as np
 import torch
 
@@ -119,13 +121,20 @@ def run_case(afiv, c):
     iv, fl = iv.cpu().numpy(), fl.cpu().numpy()
     iv_o = oracle.implied_vol_grid(ref, logm, tau, spot, r, q, oracle_variant(v))
     if v != "B":
-        assert_iv_close(iv, iv_o, logm, tau, spot, r, q, max_ill_mismatch=0.01, same_path=v == "A_BRENT")
+        assert_iv_close(iv, iv_o, logm, tau, spot, r, q, same_path=v == "A_BRENT")
     else:
+        # the spot form is solved on brentq's own path: over the 91 spot-form trials of the fixed seed
+        # range (860 000 roots) no NaN mask differs and no root is further than 1e-9 from the oracle's
         mism = np.isnan(iv) != np.isnan(iv_o)
-        assert mism.mean() <= 0.01, f"variant B NaN mask differs at {mism.sum()} points"
+        assert not mism.any(), f"variant B NaN mask differs at {mism.sum()} points"
         m = ~np.isnan(iv) & ~np.isnan(iv_o)
         d = np.abs(iv[m] - iv_o[m])
-        assert d.size == 0 or np.mean(d > 1e-6) <= 0.002, f"variant B: {np.sum(d > 1e-6)} of {d.size} roots differ"
+        if os.environ.get("AFIV_IV_RULE_REPORT"):
+            with open(os.environ["AFIV_IV_RULE_REPORT"], "a") as fh:
+                fh.write(f"random_lattices.py:B desc={c['desc'].replace(' ', '_')[:60]} points={iv.size} mism={int(mism.sum())} roots={d.size} "
+                         f"beyond_1e-6={int(np.sum(d > 1e-6))} beyond_1e-9={int(np.sum(d > 1e-9))} "
+                         f"max={float(d.max()) if d.size else 0.0:.3g}\n")
+        assert d.size == 0 or d.max() <= 1e-8, f"variant B: {np.sum(d > 1e-8)} of {d.size} roots differ, worst {d.max():.3g}"
     fl_o = oracle.arb_check(iv, ref, logm, tau, spot, r, q, oracle_variant(v))
     assert np.array_equal(fl, fl_o), f"flags differ in {np.sum(np.any(fl != fl_o, axis=1))} surfaces"
     iv2, fl2, ra2 = g.surface(dev(p), spot, v)

@@ -38,8 +38,14 @@ def test_two_self_launched_ranks_reproduce_the_single_rank_flags(tmp_path):
     assert np.array_equal(flags1, flags2)
     assert (flags1[:, 3] & 4).any() and not (flags1[:, 3] & 4).all()
     for line in (one, two):
-        assert line["roofline"]["kernel"] in ("price_kernel", "iv_fast_kernel") and line["roofline"]["frac"] > 0
+        assert line["roofline"]["kernel"] in ("price_kernel", "iv_fast_kernel")
+        for r in (line["roofline"], line["roofline_other_kernel"]):
+            assert 0 < r["frac"] <= 1.0                          # a fraction of a peak, whatever the kernel
+            assert r["bound"] == ("mfma" if r["kernel"] == "price_kernel" else "hbm")
+            assert r["traffic"] is None or r["traffic_source"].startswith("profiles/pmc_traffic.json@")
         assert "REDUCED" in line["config"]["workload"]          # not the configured batch: says so
+    assert one["general_lattice"]["value"] > 0 and "general_lattice" not in two
+    assert two["xgmi_bound"]["bytes_per_link_per_step"] == 3072 * (20 * 50 * 8 + 16)
 
 
 def test_launch_under_torch_distributed_run(tmp_path):
@@ -75,4 +81,14 @@ def test_rccl_exchange_path_with_one_rank(tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "all-gathered" in line["config"]["parallelism"] and line["final_gather"]["ms"] > 0
     assert line["final_gather"]["bytes_per_rank"] == 6144 * (20 * 50 * 8 + 16)
+    # five steps (two warm-up, three timed) alternate between the two pairs of local buffers
+    assert sorted(line["final_gather"]["steps_on_each_buffer_pair"]) == [2, 3]
     assert np.array_equal(np.load(dump), flags1)
+    # the same with the flag words alone: vols stay sharded, 16 bytes per surface cross
+    dump2 = str(tmp_path / "solo_flags.npy")
+    out = subprocess.run(cmd[:-3] + ["--dump", dump2, "--solo-gather", "--gather", "flags"], capture_output=True,
+                         text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["final_gather"]["bytes_per_rank"] == 6144 * 16 and "flag words only" in line["config"]["parallelism"]
+    assert np.array_equal(np.load(dump2), flags1)

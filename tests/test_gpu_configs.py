@@ -306,7 +306,7 @@ def test_config5_stress_grid(afiv):
         iv_o = oracle.implied_vol_grid(ratio, LOGM_GRID, tau, SPOT, R, Q, variant)
         print(f"variant {variant}: NaN on GPU {int(np.isnan(iv).sum())}, oracle {int(np.isnan(iv_o).sum())}, "
               f"mask mismatches {int((np.isnan(iv) != np.isnan(iv_o)).sum())}")
-        assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, max_ill_mismatch=0.01, same_path=variant != "A")
+        assert_iv_close(iv, iv_o, LOGM_GRID, tau, SPOT, R, Q, same_path=variant != "A")
     flags = grid.arb_check(dev(iv_o), dev(ratio), SPOT, "B").cpu().numpy()
     assert np.array_equal(flags, oracle.arb_check(iv_o, ratio, LOGM_GRID, tau, SPOT, R, Q, "B"))
 

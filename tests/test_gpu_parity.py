@@ -10,15 +10,16 @@ Tolerances (from the north-star statement, made well-posed):
           sigma_v^2 of 1 by sigma_v^2, so any double-precision evaluation of it AS WRITTEN
           (QuantLib's, the oracle's) carries an absolute noise of about eps / sigma_v^2 -- below
           the first term for sigma_v >= 0.06, 3.6e-9 at the calibration bound sigma_v = 1e-3.
-  IV      |d| <= 1e-6 absolute and identical NaN masks wherever the inversion is well
+  IV      identical NaN masks, and |d| <= 1e-6 absolute wherever the inversion is well
           conditioned (Black-Scholes vega >= 1e-3 in spot units, i.e. a one-ulp change of a
-          21000-scale price moves the root by < 1e-8).  Below that, SciPy's own Cephes erfc and
-          the C library's differ by an ulp and Brent's path -- even the bracket test -- flips:
-          there a vol must either agree to 1e-6 or RE-PRICE to the reference vol's value within
+          21000-scale price moves the root by < 1e-8).  The kernels that walk brentq's own path
+          (variants "A_BRENT", "B") are held to 1e-8 at EVERY point, well conditioned or not.  The
+          forward form's own solver converges to the root instead of following brentq: below that
+          vega a vol must either agree to 1e-6 or RE-PRICE to the reference vol's value within
           the rounding of the objective's own terms (64 eps F exp(-r tau)): where the time value
           is below an ulp of the price a whole interval of vols solves the equation in double
-          precision, and which of them a root finder returns depends on its path.  The kernels
-          that walk brentq's path (variants "A_BRENT", "B") are additionally held to 1e-4 there.
+          precision, and which of them a root finder returns depends on its path.  Only the
+          SciPy-made golden set names exceptions (see assert_iv_close and its caller there).
   flags   bit-exact given identical IV / ratio inputs
   decode  float32, |d| <= 2e-5 * max(1, |x|) (summation order differs from torch's GEMM)
 """
@@ -83,9 +84,17 @@ def oracle_variant(variant):
     return "A" if variant == "A_BRENT" else variant
 
 
-def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002, same_path=True):
-    """IV parity rule of the module docstring.  ``same_path``: the kernel walks brentq's own
-    iterations, so even ill-conditioned roots are expected within 1e-4."""
+def assert_iv_close(got, ref, logm, tau, spot, r, q, same_path=True, max_mismatch=0, ill_tol=1e-8):
+    """IV parity rule of the module docstring, with the allowances the census of
+    tools/gpu_iv_rule_census.py left standing (1.6 M points over every call site of this function):
+      * NaN masks: identical.  ``max_mismatch`` is a COUNT of points, zero unless a caller names its
+        points (one bracket test of the SciPy-made golden set flips with the last bit of erfc);
+      * Black-Scholes vega >= 1e-3: within the reference's 1e-6 -- within 1e-8 for the kernels that
+        walk brentq's own path (``same_path``), which land on the oracle's root;
+      * below that vega: ``same_path`` kernels within ``ill_tol`` all the same (3e-11 observed against
+        the C oracle); the forward form's own solver must agree to 1e-6 or re-price to the oracle
+        vol's value within 64 eps F exp(-r tau) -- where the time value is below an ulp of the price
+        a whole interval of vols solves the equation in double precision (a sixth of such points)."""
     v_ref = vega(ref, logm, tau, spot, r, q)
     v_got = vega(got, logm, tau, spot, r, q)
     v = np.where(np.isnan(v_ref), v_got, v_ref)
@@ -94,10 +103,10 @@ def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002, sam
     mism = np.isnan(got) != np.isnan(ref)
     # a point that is NaN on both sides has no vega; it agrees by definition
     assert not np.any(mism & well), f"NaN mask differs at {np.sum(mism & well)} well-conditioned points"
-    assert np.mean(mism) <= max_ill_mismatch, f"NaN mask differs at {np.sum(mism)} points"
+    assert np.sum(mism) <= max_mismatch, f"NaN mask differs at {np.sum(mism)} points"
     m = well & ~both_nan & ~mism
     d = np.abs(got[m] - ref[m])
-    assert d.size == 0 or d.max() <= 1e-6, f"max IV difference {d.max():.3g}"
+    assert d.size == 0 or d.max() <= (1e-8 if same_path else 1e-6), f"max IV difference {d.max():.3g}"
     m2 = ~well & ~both_nan & ~mism
     d2 = np.abs(got - ref)
     if os.environ.get("AFIV_IV_RULE_REPORT"):
@@ -109,7 +118,7 @@ def assert_iv_close(got, ref, logm, tau, spot, r, q, max_ill_mismatch=0.002, sam
                      f"ill_beyond_1e-6={int(np.sum(m2 & (d2 > 1e-6)))} "
                      f"ill_max={float(d2[m2].max()) if m2.any() else 0.0:.3g} well_max={float(d.max()) if d.size else 0.0:.3g}\n")
     if same_path:
-        assert not m2.any() or d2[m2].max() <= 1e-4, f"ill-conditioned IV difference {d2[m2].max():.3g}"
+        assert not m2.any() or d2[m2].max() <= ill_tol, f"ill-conditioned IV difference {d2[m2].max():.3g}"
     else:
         p_got, unit = reprice_a(got, logm, tau, spot, r, q)
         p_ref, _ = reprice_a(ref, logm, tau, spot, r, q)
@@ -227,7 +236,11 @@ def test_implied_vol_matches_scipy_golden(afiv, grid821, golden_dir, variant):
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         m = ~np.isnan(ref)
         assert np.all(np.abs(got[m] - ref[m]) <= 1e-6)
-    assert_iv_close(got, ref, LOGM_GRID, T_GRID, float(g["spot"]), R, Q, same_path=variant != "A")
+    # SciPy's own brentq made these vols, with Cephes' erfc where the kernels have their erfcx table:
+    # the two differ by an ulp, which flips ONE bracket test of the 10 584 (a NaN on one side only)
+    # and moves three ill-conditioned roots of the Brent-path kernels by up to 1.5e-6
+    assert_iv_close(got, ref, LOGM_GRID, T_GRID, float(g["spot"]), R, Q, same_path=variant != "A",
+                    max_mismatch=0 if variant == "B" else 1, ill_tol=1e-5)
 
 
 @pytest.mark.parametrize("variant", ["A", "A_BRENT", "B"])
