@@ -99,7 +99,7 @@ try {
     const size_t n_sym = sym ? (size_t)2 * AFIV_NQ_NODES * nHpad : 0;
     const size_t n_const = ((size_t)8 * nT + (size_t)2 * nK + (size_t)AFIV_KDIM * nKpad + n_sym + 3) / 4 * 4;
     const size_t n_order = ((size_t)nT * nK * sizeof(unsigned short) + 31) / 32 * 4;   // in doubles, 32-byte multiple
-    const size_t n_prog = AFIV_MAX_MATURITIES / 8;                                     // one byte per maturity
+    const size_t n_prog = AFIV_MAX_MATURITIES / 8 + AFIV_MAX_MATURITIES;               // one byte per maturity, then one word
     const size_t nd = n_const + n_order + n_prog;
     std::vector<double> h(nd, 0.0);
     double *p_tau = h.data(), *p_term = p_tau + nT, *p_dd = p_term + nT, *p_Dq = p_dd + nT,
@@ -236,7 +236,9 @@ try {
         }
     }
     unsigned char prog[AFIV_MAX_MATURITIES] = {0};
+    unsigned long long need[AFIV_MAX_MATURITIES] = {0};
     v.prog = reinterpret_cast<const unsigned char *>(dev + n_const + n_order);
+    v.need = reinterpret_cast<const unsigned long long *>(dev + n_const + n_order + AFIV_MAX_MATURITIES / 8);
     if (trunc_days && v.step_count == 0 && nT >= 2) {
         // Maturities that are sums of earlier ones: 1 - exp(-d (Tx + Ty)) = ox + oy - ox oy costs six
         // instructions where a direct evaluation costs an exp and a sincos.  A thread can keep the
@@ -297,8 +299,35 @@ try {
                     a = f / S;
                     b = f % S;
                 }
-                // (the block is already on the device: this small piece follows it)
-                if (hipMemcpy(dev + n_const + n_order, prog, sizeof(prog), hipMemcpyHostToDevice) != hipSuccess) {
+                // Which earlier values does a walk that starts at maturity t0 descend from?  Sources of
+                // every step in the full walk, then the transitive closure below t0.
+                {
+                    std::vector<int> src0(nT, -1), src1(nT, -1);
+                    int la = -1, lb = -1;                 // maturities whose values sit in A and B
+                    for (int t = 0; t < nT; ++t) {
+                        const int op = prog[t] & 15, pv = t - 1;
+                        const int pick[7][2] = {{-1, -1}, {pv, pv}, {pv, la}, {pv, lb}, {la, la}, {la, lb}, {lb, lb}};
+                        src0[t] = pick[op][0];
+                        src1[t] = pick[op][1];
+                        if ((prog[t] >> 4) == 1) la = t;
+                        if ((prog[t] >> 4) == 2) lb = t;
+                    }
+                    for (int t0 = 1; t0 < nT; ++t0) {
+                        unsigned long long mask = 0;
+                        for (int t = t0; t < nT; ++t)
+                            for (int sidx : {src0[t], src1[t]})
+                                if (sidx >= 0 && sidx < t0) mask |= 1ull << sidx;
+                        for (int t = t0 - 1; t >= 0; --t)          // sources lie below their users
+                            if ((mask >> t) & 1ull)
+                                for (int sidx : {src0[t], src1[t]})
+                                    if (sidx >= 0) mask |= 1ull << sidx;
+                        need[t0] = mask;
+                    }
+                }
+                // (the block is already on the device: these small pieces follow it)
+                if (hipMemcpy(dev + n_const + n_order, prog, sizeof(prog), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(dev + n_const + n_order + AFIV_MAX_MATURITIES / 8, need, sizeof(need),
+                              hipMemcpyHostToDevice) != hipSuccess) {
                     if (g->workspace) (void)hipFree(g->workspace);
                     (void)hipFree(dev); delete g; return AFIV_E_HIP;
                 }

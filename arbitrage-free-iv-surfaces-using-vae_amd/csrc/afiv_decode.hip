@@ -13,18 +13,18 @@
 namespace {
 
 constexpr int TS = 16;            // samples per tile
-constexpr int THREADS = 128;
 constexpr int W1 = 12 * 32, W2 = 32 * 64, W3 = 64 * 128, W4 = 128 * 5;
 constexpr int WTOTAL = W1 + 3 * 32 + W2 + 3 * 64 + W3 + 3 * 128 + W4 + 5;
 
 // out[s][o] = act(b[o] + sum_i in[s][i] * w[i*OUT + o]) for the tile; thread = (o, sample group)
 // packed layout per hidden layer: w[IN*OUT], b[OUT], scale[OUT], shift[OUT]
-template <int IN, int OUT, int SPT, bool HIDDEN>
+template <int IN, int OUT, int SPT, bool HIDDEN, int THREADS>
 __device__ __forceinline__ void layer(const float *__restrict__ w,
                                       const float *__restrict__ in /*[TS][IN]*/, float *__restrict__ out /*[TS][OUT]*/,
                                       int tid)
 {
     constexpr int GROUPS = TS / SPT;
+    static_assert(OUT * GROUPS <= THREADS, "one (neuron, sample group) per thread");
     if (tid < OUT * GROUPS) {
         const int o = tid % OUT;
         const int s0 = (tid / OUT) * SPT;
@@ -46,6 +46,12 @@ __device__ __forceinline__ void layer(const float *__restrict__ w,
     }
 }
 
+// THREADS = 128 with 4 / 8 / 16 samples per thread in the three hidden layers: every weight read
+// feeds up to sixteen multiply-adds, the shape for batches that fill the chip.  THREADS = 512 with
+// 1 / 2 / 4 samples per thread: four times the lanes on the same tile, for batches of fewer tiles
+// than CUs, where a call's time is one tile's latency (100 samples: 11 -> us).  Same arithmetic
+// per output either way (one accumulation chain per (sample, neuron), inputs in order).
+template <int THREADS, int S1, int S2, int S3>
 __global__ __launch_bounds__(THREADS) void decode_kernel(DecoderView d, const float *__restrict__ z,
                                                          const float *__restrict__ c, int64_t N, int64_t c_rows,
                                                          float *__restrict__ norm_out, float *__restrict__ p32,
@@ -73,13 +79,13 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecoderView d, const fl
             bufA[s * 12 + f] = v;
         }
         __syncthreads();
-        layer<12, 32, 4, true>(l1, bufA, bufB, tid);
+        layer<12, 32, S1, true, THREADS>(l1, bufA, bufB, tid);
         __syncthreads();
-        layer<32, 64, 8, true>(l2, bufB, bufA, tid);
+        layer<32, 64, S2, true, THREADS>(l2, bufB, bufA, tid);
         __syncthreads();
-        layer<64, 128, 16, true>(l3, bufA, bufB, tid);
+        layer<64, 128, S3, true, THREADS>(l3, bufA, bufB, tid);
         __syncthreads();
-        layer<128, 5, 1, false>(l4, bufB, bufA, tid);
+        layer<128, 5, 1, false, THREADS>(l4, bufB, bufA, tid);
         __syncthreads();
         if (tid < TS * 5) {
             const int s = tid / 5, f = tid - s * 5;
@@ -105,7 +111,11 @@ int afiv_launch_decode(const DecoderView &d, const float *z, const float *c, int
     if (N <= 0) return 0;
     int64_t tiles = (N + TS - 1) / TS;
     int64_t blocks = tiles < 256 * 2 ? tiles : 256 * 2;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, d, z, c, N, c_rows,
-                       normalized_out, p32, p64);
+    if (tiles < 256)
+        hipLaunchKernelGGL((decode_kernel<512, 1, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, s, d, z, c, N, c_rows,
+                           normalized_out, p32, p64);
+    else
+        hipLaunchKernelGGL((decode_kernel<128, 4, 8, 16>), dim3((unsigned)blocks), dim3(128), 0, s, d, z, c, N, c_rows,
+                           normalized_out, p32, p64);
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

@@ -44,7 +44,10 @@ struct GridView {
     // Low nibble: 0 = evaluated directly, else the product form of two earlier values, each the
     // previous maturity's (P) or one of two saved ones (A, B): 1 = P P, 2 = P A, 3 = P B, 4 = A A,
     // 5 = A B, 6 = B B.  High nibble: 1 / 2 = keep this maturity's value as A / B.
-    const unsigned char *prog;     // [nT rounded up to 8] device bytes
+    const unsigned char *prog;     // [AFIV_MAX_MATURITIES] device bytes
+    // need[t0] = the maturities below t0 whose values the steps from t0 on descend from (bit t): what a
+    // workgroup that starts its walk at maturity t0 replays first
+    const unsigned long long *need;   // [AFIV_MAX_MATURITIES] device words
     const unsigned short *order;   // [nT*nK] lattice points by decreasing |log(F/K)|/sqrt(tau): the order
                                    // in which the implied-vol kernel hands points to lanes (points far
                                    // from the money need the most root-finder iterations; served first,

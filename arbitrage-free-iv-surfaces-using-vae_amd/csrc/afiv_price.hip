@@ -293,8 +293,9 @@ __device__ __forceinline__ double2 cf_eval(const JState &s, const Model &m, doub
 // 1 - exp(-d T_t) follows from two earlier values by the same product form, as the grid's program
 // says; the thread keeps the previous maturity's value and two saved ones in the registers that hold
 // the step factors of NFAC = 2.  A workgroup that starts in the middle of the term structure (small
-// batches split their maturities over several workgroups) first replays the program's earlier
-// steps, exponentials only, so its results are those of an unsplit walk bit for bit.
+// batches split their maturities over several workgroups) first replays those of the program's
+// earlier steps that its own values descend from (GridView::need), exponentials only, so its
+// results are those of an unsplit walk bit for bit.
 //
 // SYM: the strikes are symmetric about the forward-free money line (log K_k = -log K_{nK-1-k}, as
 // in linspace(-a, a, n)), so cos(x log K) is shared and sin(x log K) only changes sign between a
@@ -399,7 +400,11 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                 typedef const unsigned __attribute__((address_space(4))) *prog_ptr;
                 const prog_ptr pw = (prog_ptr)(unsigned long long)(const void *)g.prog;
                 const afivm::coef_ptr tm = (afivm::coef_ptr)(unsigned long long)(const void *)g.term;
+                typedef const unsigned long long __attribute__((address_space(4))) *need_ptr;
+                // only the maturities this part's values descend from
+                const unsigned long long need = ((need_ptr)(unsigned long long)(const void *)g.need)[tile_lo * MT];
                 for (int t = 0; t < tile_lo * MT; ++t) {
+                    if (!((need >> t) & 1ull)) continue;
                     const unsigned op = (pw[t >> 2] >> (8 * (t & 3))) & 0xffu;
                     const double T = tm[t];
                     prog_step(op, ex0, fa0, fb0, st0.d, T, sct);

@@ -640,13 +640,17 @@ def test_small_batches_replay_the_program_without_changing_a_bit(afiv):
     """A small batch on the reference's term structure splits its maturities over several workgroups,
     each of which replays the earlier steps of the sum-of-maturities program first: the rows equal
     those of a large call bit for bit."""
-    grid = afiv.Grid(LOGM_GRID, T_GRID, R, Q)
-    assert grid.traits["stepped"] == 3
     p = dev(sample_params(3000, 23))
-    big = grid.price(p)
-    for n in (1, 6, 7, 8, 100, 700, 896, 903):
-        small = grid.price(p[:n].contiguous())
-        assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), n
+    lattices = [T_GRID] + [(np.array(days) + 0.25) / 365.0 for days in
+                           ([7, 14, 30, 60], [60, 30, 90, 120, 240], [30, 30, 60, 60, 120, 180, 240, 300, 360, 720],
+                            [5, 10, 20, 40, 80, 160, 320, 640, 645, 650, 660, 1300])]
+    for tau in lattices:
+        grid = afiv.Grid(LOGM_GRID, tau, R, Q)
+        assert grid.traits["stepped"] == 3
+        big = grid.price(p)
+        for n in (1, 6, 7, 8, 100, 700, 896, 903):
+            small = grid.price(p[:n].contiguous())
+            assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), (n, len(tau))
 
 
 def test_stepped_exponential_on_evenly_spaced_exact_year_fractions(afiv):
