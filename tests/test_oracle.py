@@ -35,7 +35,7 @@ def test_pricing_restatement_reproduces_stored_quantlib_objectives(pin):
       1e-9.  The remainder differs by up to 5e-3 of the density-Wasserstein term, which divides
       second differences of prices by dlm^2 = 1/1.5e4 and clips them at zero; those days sit at
       |rho| near the optimiser's bound and are shown not to be a pricing difference by
-      test_unreproduced_day_is_not_a_pricing_difference below.
+      test_unreproduced_days_are_not_a_pricing_difference below.
     * days whose guard trips here but did not in QuantLib (deep out-of-the-money prices of 1e-17
       carry a rounding-noise sign; 55 days) and the 5 days that carry the previous day's
       parameters (:537-549) are counted, not judged."""
