@@ -57,6 +57,7 @@ SIGNATURES = {
     "afiv_density_wasserstein": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
                                          c_void_p]),
     "afiv_ensemble_stats": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+    "afiv_ensemble_stats_groups": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p]),
     "afiv_debug_math": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
 }
 

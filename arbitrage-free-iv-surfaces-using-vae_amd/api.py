@@ -270,11 +270,12 @@ ENSEMBLE_ONE_SWEEP = 16384     # afiv.h: larger ensembles take several sweeps ov
 STATIC_SCRATCH_DOUBLES = 4 * 1024 * 1024
 
 
-def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torch.Tensor:
+def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None, groups: int | None = None) -> torch.Tensor:
     """nan-aware mean, median, 5th and 95th percentile over the leading (sample) axis of a stack
     of surfaces [N, ...] -> [4, ...] (generate_iv_surface_by_date.py:474-478; NumPy's default
     percentile method).  ``select`` is an optional [N] bool / uint8 tensor of the surfaces to
-    include."""
+    include.  With ``groups`` the stack is that many consecutive ensembles of N / groups surfaces
+    (the samples of each date of a batch over dates) and the result is [groups, 4, ...]."""
     v = iv.contiguous()
     if v.dtype != torch.float64 or not v.is_cuda or v.dim() < 2:
         raise TypeError("iv must be a CUDA float64 tensor [N, ...]")
@@ -282,14 +283,21 @@ def ensemble_stats(iv: torch.Tensor, select: torch.Tensor | None = None) -> torc
     points = v[0].numel()
     if n < 1 or points < 1:
         raise ValueError(f"ensemble_stats needs at least one surface and one grid point, got {tuple(v.shape)}")
+    if groups is not None and (groups < 1 or n % groups):
+        raise ValueError(f"{n} surfaces do not split into {groups} equal groups")
     sel = None
     if select is not None:
         sel = select.to(device=v.device, dtype=torch.uint8).contiguous()
         if sel.shape != (n,):
             raise ValueError(f"select must be [{n}], got {tuple(sel.shape)}")
-    out = torch.empty((4,) + tuple(v.shape[1:]), dtype=torch.float64, device=v.device)
+    shape = (4,) + tuple(v.shape[1:])
+    out = torch.empty(shape if groups is None else (groups,) + shape, dtype=torch.float64, device=v.device)
     with torch.cuda.device(v.device):
-        rc = _lib.lib().afiv_ensemble_stats(_ptr(v), _ptr(sel), n, points, _ptr(out), _stream())
+        if groups is None:
+            rc = _lib.lib().afiv_ensemble_stats(_ptr(v), _ptr(sel), n, points, _ptr(out), _stream())
+        else:
+            rc = _lib.lib().afiv_ensemble_stats_groups(_ptr(v), _ptr(sel), groups, n // groups, points, _ptr(out),
+                                                       _stream())
     _lib.check(rc, "afiv_ensemble_stats")
     return out
 

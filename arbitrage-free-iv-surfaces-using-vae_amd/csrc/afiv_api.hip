@@ -594,7 +594,16 @@ int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int6
 {
     if (!iv || !stats_out) return AFIV_E_NULL;
     if (N < 1 || N > (int64_t)1 << 31 || points < 1 || points > (1 << 24)) return AFIV_E_SHAPE;
-    return afiv_launch_ensemble(iv, select, N, (int)points, stats_out, as_stream(stream));
+    return afiv_launch_ensemble(iv, select, N, (int)points, 1, stats_out, as_stream(stream));
+}
+
+int afiv_ensemble_stats_groups(const double *iv, const uint8_t *select, int64_t groups, int64_t N, int64_t points,
+                               double *stats_out, void *stream)
+{
+    if (!iv || !stats_out) return AFIV_E_NULL;
+    if (groups < 0 || N < 1 || N > (int64_t)1 << 31 || points < 1 || points > (1 << 24)) return AFIV_E_SHAPE;
+    if (groups == 0) return AFIV_OK;
+    return afiv_launch_ensemble(iv, select, N, (int)points, groups, stats_out, as_stream(stream));
 }
 
 int afiv_debug_math(int op, const double *x, const double *y, int64_t n, double *out0, double *out1,

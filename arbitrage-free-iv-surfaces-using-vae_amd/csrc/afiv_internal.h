@@ -122,7 +122,7 @@ int afiv_launch_surface_iv(const GridView &g, const double *ratio, int64_t N, do
                            double *iv_out, int32_t *flags, hipStream_t s);
 int afiv_launch_fast_iv(const GridView &g, const double *ratio, int64_t N, double spot, double *iv_out,
                         int32_t *flags, hipStream_t s);
-int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
+int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, int64_t segments, double *out,
                          hipStream_t s);
 int afiv_launch_density_wasserstein(const GridView &g, const double *model_ratio, int64_t C,
                                     const double *market_ratio, int64_t D, double *scratch, double *dist,

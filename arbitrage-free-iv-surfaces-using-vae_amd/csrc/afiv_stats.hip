@@ -35,16 +35,24 @@ __device__ double numpy_linear_quantile(const double *v, int m, double q)
     return r;
 }
 
-__global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__restrict__ iv,
-                                                                const uint8_t *__restrict__ select, int64_t N,
-                                                                int per, int padded, double *__restrict__ out)
+// `segments` consecutive groups of N surfaces each get their own statistics (out [segments][4][per]):
+// one launch for, say, the 100 samples of each of 500 dates.
+__global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__restrict__ iv_all,
+                                                                const uint8_t *__restrict__ select_all, int64_t N,
+                                                                int per, int padded, int64_t segments,
+                                                                double *__restrict__ out_all)
 {
     extern __shared__ double vals[];              // [padded]
     __shared__ int wave_count[STAT_THREADS / 64];
     __shared__ int total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double inf = __builtin_inf();
-    for (int p = blockIdx.x; p < per; p += gridDim.x) {
+    for (int64_t item = blockIdx.x; item < segments * per; item += gridDim.x) {
+        const int64_t seg = item / per;
+        const int p = (int)(item - seg * per);
+        const double *__restrict__ iv = iv_all + seg * N * per;
+        const uint8_t *__restrict__ select = select_all ? select_all + seg * N : nullptr;
+        double *__restrict__ out = out_all + seg * 4 * per;
         __syncthreads();
         if (tid == 0) total = 0;
         __syncthreads();
@@ -113,7 +121,8 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__
 
 // ---- ensembles larger than one LDS-resident column ---------------------------------------------
 // The same four statistics, bit for bit, for any number of surfaces, without scratch memory.  One
-// workgroup owns TILE_P adjacent grid points (one 64-byte line of every surface row) and streams
+// workgroup owns TILE_P adjacent grid points (half a 64-byte line of every surface row; the workgroup
+// next door reads the other half at about the same time, out of L2) and streams
 // the stack several times:
 //   sweep 1   count of usable values, their sum in sample order (the order NumPy adds the rows of a
 //             leading axis in, so the mean is np.nanmean's), and the smallest / largest value;
@@ -128,13 +137,14 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__
 //             counting: value v is the k-th smallest iff #(values < v) <= k < #(values <= v).
 // Selection is exact, so the interpolated statistics equal NumPy's whatever its partition does.
 // Three sweeps for 50 000 surfaces, four for a million; each reads every value once, coalesced.
-constexpr int TILE_P = 8;
+constexpr int TILE_P = 4;
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_ROWS = SEL_THREADS / TILE_P;     // rows per sweep step
-constexpr int SEL_BLOCK = 8 * SEL_ROWS;            // rows staged per block of the in-order sum
+constexpr int SEL_BLOCK = 8 * SEL_ROWS;            // rows staged per block of the in-order sum: eight per thread
 constexpr int SEL_BINS = 256;
 constexpr int SEL_TARGETS = 6;
 constexpr int SEL_CAP = 256;
+constexpr int SEL_UNROLL = 16;                     // loads in flight per lane in the narrowing sweeps
 
 __device__ __forceinline__ unsigned long long order_key(double x)
 {
@@ -145,6 +155,47 @@ __device__ __forceinline__ double key_value(unsigned long long k)
 {
     const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
+}
+
+// The values of U consecutive surfaces i0 .. i0 + U - 1 at grid point p, NaN where the row is past the
+// end or not selected.  A thread takes consecutive rows so that their selection bytes are ONE 8- or
+// 16-byte load where alignment and range allow (a byte load per value doubled the vector-memory
+// instructions of a sweep, which is what bounds it); values and bytes are loaded side by side, so
+// unselected rows cost their bandwidth but no second round of latency.
+template <int U>
+__device__ __forceinline__ void masked_rows(const double *__restrict__ iv, const uint8_t *__restrict__ select,
+                                            int64_t i0, int64_t N, int per, int p, bool have_p, double (&x)[U])
+{
+    static_assert(U == 8 || U == 16, "one 8- or 16-byte load of selection bytes");
+    const double nan = __builtin_nan("");
+    const int pc = have_p ? p : 0;
+    unsigned sel[U / 4];
+#pragma unroll
+    for (int w = 0; w < U / 4; ++w) sel[w] = 0x01010101u;
+    bool bytewise = false;
+    if (select) {
+        const uint8_t *sp = select + i0;
+        if (i0 + U <= N && (reinterpret_cast<unsigned long long>(sp) & (U - 1)) == 0) {
+            if (U == 8) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(sp);
+                sel[0] = v.x; sel[1] = v.y;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4 *>(sp);
+                sel[0] = v.x; sel[1] = v.y; sel[U / 4 - 2] = v.z; sel[U / 4 - 1] = v.w;
+            }
+        } else {
+            bytewise = true;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u;
+        const bool in = have_p && i < N;
+        const double v = iv[(in ? i : 0) * per + pc];
+        bool keep = ((sel[u / 4] >> (8 * (u % 4))) & 0xffu) != 0;
+        if (bytewise) keep = i < N && select[i] != 0;
+        x[u] = in && keep ? v : nan;
+    }
 }
 
 struct SelTarget {
@@ -158,8 +209,10 @@ struct SelTarget {
     double value;
 };
 
+// shift = -1 marks a slot that is switched off
 __device__ __forceinline__ bool in_interval(unsigned long long key, unsigned long long lo, int shift)
 {
+    if (shift < 0) return false;
     return shift >= 64 ? true : ((key - lo) >> shift) == 0 && key >= lo;
 }
 
@@ -167,8 +220,8 @@ __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const doub
                                                                       const uint8_t *__restrict__ select, int64_t N,
                                                                       int per, double *__restrict__ out)
 {
-    // histograms [TILE_P][SEL_TARGETS][SEL_BINS] u32 (48 KB), later candidate lists
-    // [TILE_P][SEL_TARGETS][SEL_CAP] doubles (96 KB); the in-order sum's staging block shares it
+    // histograms [TILE_P][SEL_TARGETS][SEL_BINS] u32 (24 KB), later candidate lists
+    // [TILE_P][SEL_TARGETS][SEL_CAP] doubles (48 KB); the in-order sum's staging block shares it
     __shared__ __attribute__((aligned(16))) unsigned char pool[TILE_P * SEL_TARGETS * SEL_CAP * sizeof(double)];
     __shared__ SelTarget tg[TILE_P][SEL_TARGETS];
     __shared__ unsigned long long kmin[TILE_P], kmax[TILE_P];
@@ -193,12 +246,12 @@ __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const doub
         unsigned long long mn = ~0ull, mx = 0ull;
         long long c = 0;
         for (int64_t base = 0; base < N; base += SEL_BLOCK) {
+            double xb[8];
+            masked_rows<8>(iv, select, base + rl * 8, N, per, p, have_p, xb);
 #pragma unroll
-            for (int u = 0; u < SEL_BLOCK / SEL_ROWS; ++u) {
-                const int64_t i = base + u * SEL_ROWS + rl;
-                double x = nan;
-                if (have_p && i < N && (!select || select[i])) x = iv[i * per + p];
-                stage[(u * SEL_ROWS + rl) * TILE_P + pt] = x;
+            for (int u = 0; u < 8; ++u) {
+                const double x = xb[u];
+                stage[(rl * 8 + u) * TILE_P + pt] = x;
                 if (x == x) {
                     const unsigned long long k = order_key(x);
                     mn = k < mn ? k : mn;
@@ -208,11 +261,15 @@ __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const doub
             }
             __syncthreads();
             if (tid < TILE_P) {
+                // the in-order sum: one dependent chain per point, its operands read eight ahead
+                // (rows past the end were staged as NaN and drop out like every other NaN)
                 double sacc = sum[tid];
-                const int rows = (int)(N - base < SEL_BLOCK ? N - base : SEL_BLOCK);
-                for (int r = 0; r < rows; ++r) {
-                    const double x = stage[r * TILE_P + tid];
-                    if (x == x) sacc += x;
+                for (int r0 = 0; r0 < SEL_BLOCK; r0 += 8) {
+                    double x[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r] = stage[(r0 + r) * TILE_P + tid];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sacc = x[r] == x[r] ? sacc + x[r] : sacc;
                 }
                 sum[tid] = sacc;
             }
@@ -272,26 +329,31 @@ __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const doub
             __syncthreads();
             if (!again) break;
             // this point's intervals still to be narrowed (aliases removed), in registers
+            // (slot a = target a itself, switched off where it is done, small enough or an alias: static
+            // indices keep the three arrays in registers)
             unsigned long long lo[SEL_TARGETS];
-            int sh[SEL_TARGETS];
-            int nsel = 0, slot[SEL_TARGETS];
+            int sh[SEL_TARGETS], slot[SEL_TARGETS];
+            constexpr int nsel = SEL_TARGETS;
+#pragma unroll
             for (int j = 0; j < SEL_TARGETS; ++j) {
                 const SelTarget &t = tg[pt][j];
-                if (!t.done && t.count > SEL_CAP && t.alias == j) {
-                    lo[nsel] = t.lo;
-                    sh[nsel] = t.shift;
-                    slot[nsel] = j;
-                    ++nsel;
-                }
+                const bool on = !t.done && t.count > SEL_CAP && t.alias == j;
+                lo[j] = on ? t.lo : ~0ull;                 // an empty interval: lo = 2^64 - 1, shift = 0 holds one key
+                sh[j] = on ? t.shift : -1;                 // ... and shift = -1 none at all (see in_interval)
+                slot[j] = j;
             }
-            for (int64_t base = 0; base < N; base += SEL_ROWS) {
-                const int64_t i = base + rl;
-                if (have_p && i < N && (!select || select[i])) {
-                    const double x = iv[i * per + p];
+            // eight independent loads in flight per lane: a sweep is bound by memory latency otherwise
+            for (int64_t base = 0; base < N; base += SEL_ROWS * SEL_UNROLL) {
+                double xs[SEL_UNROLL];
+                masked_rows<SEL_UNROLL>(iv, select, base + (int64_t)rl * SEL_UNROLL, N, per, p, have_p, xs);
+#pragma unroll
+                for (int u = 0; u < SEL_UNROLL; ++u) {
+                    const double x = xs[u];
                     if (x == x) {
                         const unsigned long long k = order_key(x);
-                        for (int a = 0; a < nsel; ++a)
-                            if (in_interval(k, lo[a], sh[a])) {
+#pragma unroll
+                        for (int a = 0; a < SEL_TARGETS; ++a)        // (fully unrolled: the arrays stay in registers)
+                            if (a < nsel && in_interval(k, lo[a], sh[a])) {
                                 const int down = sh[a] > 8 ? sh[a] - 8 : 0;
                                 const unsigned bin = (unsigned)((k - lo[a]) >> down) & (SEL_BINS - 1);
                                 atomicAdd(&hist[(pt * SEL_TARGETS + slot[a]) * SEL_BINS + bin], 1u);
@@ -337,26 +399,30 @@ __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const doub
         __syncthreads();
         {
             unsigned long long lo[SEL_TARGETS];
-            int sh[SEL_TARGETS];
-            int nsel = 0, slot[SEL_TARGETS];
+            int sh[SEL_TARGETS], slot[SEL_TARGETS];
+            constexpr int nsel = SEL_TARGETS;
+            bool any = false;
+#pragma unroll
             for (int j = 0; j < SEL_TARGETS; ++j) {
                 const SelTarget &t = tg[pt][j];
-                if (!t.done && t.alias == j) {
-                    lo[nsel] = t.lo;
-                    sh[nsel] = t.shift;
-                    slot[nsel] = j;
-                    ++nsel;
-                }
+                const bool on = !t.done && t.alias == j;
+                lo[j] = on ? t.lo : ~0ull;
+                sh[j] = on ? t.shift : -1;
+                slot[j] = j;
+                any |= on;
             }
-            if (nsel)
-                for (int64_t base = 0; base < N; base += SEL_ROWS) {
-                    const int64_t i = base + rl;
-                    if (have_p && i < N && (!select || select[i])) {
-                        const double x = iv[i * per + p];
+            if (any)
+                for (int64_t base = 0; base < N; base += SEL_ROWS * SEL_UNROLL) {
+                    double xs[SEL_UNROLL];
+                    masked_rows<SEL_UNROLL>(iv, select, base + (int64_t)rl * SEL_UNROLL, N, per, p, have_p, xs);
+#pragma unroll
+                    for (int u = 0; u < SEL_UNROLL; ++u) {
+                        const double x = xs[u];
                         if (x == x) {
                             const unsigned long long k = order_key(x);
-                            for (int a = 0; a < nsel; ++a)
-                                if (in_interval(k, lo[a], sh[a])) {
+#pragma unroll
+                            for (int a = 0; a < SEL_TARGETS; ++a)
+                                if (a < nsel && in_interval(k, lo[a], sh[a])) {
                                     const int at = atomicAdd(&list_n[pt][slot[a]], 1);
                                     if (at < SEL_CAP) cand[(pt * SEL_TARGETS + slot[a]) * SEL_CAP + at] = x;
                                 }
@@ -536,21 +602,25 @@ int afiv_launch_density_wasserstein(const GridView &g, const double *model_ratio
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
 
-int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, double *out,
+int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int per, int64_t segments, double *out,
                          hipStream_t s)
 {
     if (N > AFIV_ENSEMBLE_ONE_SWEEP) {
         const int tiles = (per + TILE_P - 1) / TILE_P;
-        hipLaunchKernelGGL(ensemble_select_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(SEL_THREADS), 0, s,
-                           iv, select, N, per, out);
-        return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
+        for (int64_t g = 0; g < segments; ++g) {
+            hipLaunchKernelGGL(ensemble_select_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(SEL_THREADS), 0,
+                               s, iv + g * N * per, select ? select + g * N : nullptr, N, per, out + g * 4 * per);
+            if (hipGetLastError() != hipSuccess) return AFIV_E_HIP;
+        }
+        return AFIV_OK;
     }
     int padded = 2;
     while (padded < N) padded <<= 1;
     const size_t lds = (size_t)padded * sizeof(double);
     static DynLdsLimit raised;
     if (const int rc = afiv_ensure_dynamic_lds(reinterpret_cast<const void *>(&ensemble_kernel), lds, raised)) return rc;
-    hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)(per < 65536 ? per : 65536)), dim3(STAT_THREADS), lds, s, iv, select, N, per, padded,
-                       out);
+    const int64_t items = segments * per;
+    hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)(items < 65536 ? items : 65536)), dim3(STAT_THREADS), lds, s, iv, select, N,
+                       per, padded, segments, out);
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }

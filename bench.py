@@ -249,12 +249,23 @@ def run_config(which: int, steps: int, warmup: int):
             torch.cuda.synchronize()
             parts += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
         parts /= reps
+        # the statistics block of the reference (:474-478) for every date's samples, in one call
+        ok = (flags[:, 3] & 8) != 0
+        afiv.ensemble_stats(iv, ok, groups=dates)
+        se = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        se[0].record()
+        for _ in range(reps):
+            afiv.ensemble_stats(iv, ok, groups=dates)
+        se[1].record()
+        torch.cuda.synchronize()
+        stats_ms = se[0].elapsed_time(se[1]) / reps
         fl_price = pricing_flops(8, 21) * n
         out = {"config": which, "workload": f"{dates} date(s) x {per_date} samples: decode -> price -> implied vol "
                "-> checks on the reference's 8 x 21 lattice (conditioning rows of conditioning_variables_top8.csv, "
                "seeded z, the reference checkpoint's decoder weights)", "surfaces": n, "ms_per_call": ms,
                "surfaces_per_s": n / ms * 1e3, "success_frac": float(((flags[:, 3] & 8) != 0).float().mean()),
                "decode_ms": parts[0], "price_ms": parts[1], "iv_checks_ms": parts[2],
+               "per_date_statistics_ms": stats_ms,
                "pricing_frac_of_fp64_peak": fl_price / (parts[1] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                "lattice_traits": grid.traits}
     elif which == 4:

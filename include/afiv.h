@@ -241,6 +241,13 @@ int afiv_density_wasserstein(const afiv_grid *g, const double *model_ratio, int6
 int afiv_ensemble_stats(const double *iv, const uint8_t *select, int64_t N, int64_t points,
                         double *stats_out, void *stream);
 
+/* The same block for `groups` consecutive ensembles of N surfaces each in one call -- the per-date
+ * statistics of a batch over dates, where the reference runs its script (and that block) once per
+ * date: iv device [groups*N, points], select NULL or device [groups*N], stats_out device
+ * [groups,4,points].  Every group's statistics are those afiv_ensemble_stats gives for it alone. */
+int afiv_ensemble_stats_groups(const double *iv, const uint8_t *select, int64_t groups, int64_t N,
+                               int64_t points, double *stats_out, void *stream);
+
 /* ---- diagnostics: the kernels' own FP64 elementary functions, element-wise, so that unit tests
  * can check them against high-precision references.  No counterpart in the reference (which
  * calls libm / SciPy).  x, y, out0, out1: device [n]; y only for AFIV_MATH_ATAN2 (atan2(x, y));

@@ -24,7 +24,7 @@ def test_header_declares_the_expected_entry_points():
               "afiv_implied_vol", "afiv_arb_check", "afiv_implied_vol_checked", "afiv_surface", "afiv_decoder_create",
               "afiv_decoder_destroy", "afiv_decode", "afiv_arbitrage_penalty",
               "afiv_stage1_objective", "afiv_error_string", "afiv_debug_math", "afiv_surface_static",
-              "afiv_density_wasserstein", "afiv_ensemble_stats"):
+              "afiv_density_wasserstein", "afiv_ensemble_stats", "afiv_ensemble_stats_groups"):
         assert s in syms
 
 

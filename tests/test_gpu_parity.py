@@ -498,6 +498,32 @@ def test_ensemble_statistics_select_and_limits(afiv):
     assert np.array_equal(got, np.stack(oracle.ensemble_stats(big)))
 
 
+def test_grouped_ensemble_statistics_equal_each_group_alone(afiv):
+    """The per-date statistics of a batch over dates in one call: every group's four surfaces are
+    those of afiv_ensemble_stats on that group alone (hence NumPy's), with and without a mask, for
+    groups in the one-sweep range and beyond it."""
+    rng = np.random.default_rng(3)
+    for groups, n, shape in ((500, 100, (8, 21)), (3, 17000, (2, 5)), (1, 40, (3, 3))):
+        s = 0.2 + 0.05 * rng.standard_normal((groups * n,) + shape)
+        s[rng.random(s.shape) < 0.15] = np.nan
+        keep = torch.as_tensor(rng.random(groups * n) < 0.7).cuda()
+        d = dev(s)
+        for sel in (None, keep):
+            got = afiv.ensemble_stats(d, sel, groups=groups)
+            assert got.shape == (groups, 4) + shape
+            for g in (0, groups // 2, groups - 1):
+                one = afiv.ensemble_stats(d[g * n:(g + 1) * n], None if sel is None else sel[g * n:(g + 1) * n])
+                assert torch.equal(torch.nan_to_num(got[g], nan=-1.0), torch.nan_to_num(one, nan=-1.0))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = np.stack(oracle.ensemble_stats(s[:n]))
+        got0 = afiv.ensemble_stats(d, groups=groups)[0].cpu().numpy()
+        assert np.array_equal(np.nan_to_num(got0, nan=-1.0), np.nan_to_num(ref, nan=-1.0))
+    with pytest.raises(ValueError):
+        afiv.ensemble_stats(dev(np.zeros((10, 2, 2))), groups=3)
+
+
 @pytest.mark.parametrize("n,shape", [(16385, (8, 21)), (50000, (8, 21)), (50001, (3, 5)), (300000, (2, 9)),
                                      (1 << 20, (1, 8))])
 def test_large_ensembles_equal_numpy_bit_for_bit(afiv, n, shape):
