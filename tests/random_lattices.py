@@ -60,14 +60,16 @@ def oracle_noise(p, tau):
         np.maximum(1.0, (p[:, 0] * p[:, 1])[:, None, None] * np.abs(tau)[None, :, None])
 
 
-def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_points=12):
+def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_rows=3):
     """Points whose price leaves the allowance.  The kernel is held to the PLAIN rule
     1e-8 max(|C|, 1e-4) everywhere.  Where the oracle can arbitrate -- its own rounding noise
     (oracle_noise) is below a tenth of that -- it does.  Elsewhere (small sigma_v with large
     kappa theta T, and the series form the reference takes at sigma_v <= 1e-5) the oracle is the
     noisy side: the kernel is compared with a 60-digit evaluation of the same quadrature
-    (oracle/exact.py) at up to ``max_exact_points`` of those points, still by the plain rule, and
-    with the oracle only by the oracle's own noise bound.  Where the formula's value leaves the
+    (oracle/exact.py) on up to ``max_exact_rows`` whole strike rows holding such points (a row --
+    one parameter set, one maturity -- costs the 60-digit evaluation little more than one of its
+    points, since its strikes share the integrand's strike-free factor), still by the plain rule,
+    and with the oracle only by the oracle's own noise bound.  Where the formula's value leaves the
     double range both sides must agree on that.  Where it leaves the range of prices -- beyond 1e3
     in spot-1 units, a thousand times anything a call can be worth, which only the series form
     reaches: there the value is the exponential of a sum whose terms reach 1e7, so its relative
@@ -93,8 +95,14 @@ def price_bad(got, ref, p, tau, logm, r, q, trunc, max_exact_points=12):
     with np.errstate(invalid="ignore"):
         rowmax = np.max(np.where(np.isfinite(ref), np.abs(ref), 0.0), axis=2)      # [N, nT]
     if len(idx):
-        pick = idx[np.random.default_rng(len(idx)).permutation(len(idx))[:max_exact_points]]
-        ex = exact.price_ratio_points(p, logm, tau, [tuple(i) for i in pick], r, q, trunc)
+        rows = np.unique(idx[:, :2], axis=0)
+        rows = rows[np.random.default_rng(len(idx)).permutation(len(rows))[:max_exact_rows]]
+        pick, ex = [], []
+        for i, t in rows:
+            exact_row = exact.price_ratio_grid(p[i:i + 1], logm, tau[t:t + 1], r, q, trunc)[0, 0]
+            for k in np.flatnonzero(~arbitrates[i, t]):
+                pick.append((i, t, k))
+                ex.append(exact_row[k])
         for (i, t, k), e in zip(pick, ex):
             g = got[i, t, k]
             if wild(np.array(e)):
