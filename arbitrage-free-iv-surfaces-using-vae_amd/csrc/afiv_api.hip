@@ -289,8 +289,7 @@ try {
             for (int a = 0; a < S; ++a)
                 for (int b = 0; b < S; ++b)
                     if (cost[at(nT, a, b)] < best) { best = cost[at(nT, a, b)]; ba = a; bb = b; }
-            // worth a kernel of its own when at least a quarter of the direct evaluations go
-            if (best < INF && 4 * best <= 3 * nT) {
+            if (best < INF) {
                 int a = ba, b = bb;
                 for (int t = nT; t > 0; --t) {
                     const size_t j = at(t, a, b);
@@ -299,6 +298,30 @@ try {
                     a = f / S;
                     b = f % S;
                 }
+                // A product roughly adds the relative errors of its two factors exp(-d T), so a chain of
+                // k doublings carries 2^k roundings: values deeper than five products below a direct
+                // evaluation (32 roundings, 4e-15) are evaluated directly instead.  Turning a step into
+                // a direct evaluation leaves every later step valid (they use its value, not its origin).
+                std::vector<int> depth(nT, 0);
+                int la = -1, lb = -1;
+                best = 0;
+                for (int t = 0; t < nT; ++t) {
+                    const int op = prog[t] & 15, pv = t - 1;
+                    const int pick[7][2] = {{-1, -1}, {pv, pv}, {pv, la}, {pv, lb}, {la, la}, {la, lb}, {lb, lb}};
+                    if (op) {
+                        depth[t] = 1 + std::max(depth[pick[op][0]], depth[pick[op][1]]);
+                        if (depth[t] > 5) {
+                            prog[t] &= 0xf0;
+                            depth[t] = 0;
+                        }
+                    }
+                    if (!(prog[t] & 15)) ++best;
+                    if ((prog[t] >> 4) == 1) la = t;
+                    if ((prog[t] >> 4) == 2) lb = t;
+                }
+            }
+            // worth a kernel of its own when at least a quarter of the direct evaluations go
+            if (best < INF && 4 * best <= 3 * nT) {
                 // Which earlier values does a walk that starts at maturity t0 descend from?  Sources of
                 // every step in the full walk, then the transitive closure below t0.
                 {

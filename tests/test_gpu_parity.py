@@ -651,8 +651,9 @@ def test_sum_of_maturities_program_agrees_with_direct_evaluation(afiv):
     assert worst <= 2e-13, worst
     # other shapes of the same idea: unsorted, repeated and doubling maturities; a lattice without
     # any such relation is left to the direct path
+    # (a chain of doublings is cut after five products: every sixth value is evaluated directly)
     for days, want in (([7, 14, 30, 60], 3), ([60, 30, 90, 120, 240], 3), ([30, 30, 60, 60, 120], 3),
-                       ([11, 23, 47, 95, 191, 383], 0)):
+                       ([3, 6, 12, 24, 48, 96, 192, 384, 768, 1536, 3072], 3), ([11, 23, 47, 95, 191, 383], 0)):
         tau = (np.array(days) + 0.25) / 365.0
         g2 = afiv.Grid(LOGM_GRID, tau, R, Q)
         assert g2.traits["stepped"] == want, days
