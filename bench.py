@@ -235,20 +235,20 @@ def run_config(which: int, steps: int, warmup: int):
             grid.surface(p64, SPOT, "A", iv_out=iv, flags_out=flags, ratio_out=ratio)
         ms = timed(call)
         # the three kernels of a call, timed apart (events on the launch stream)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        parts = np.zeros(3)
+        # back to back, as the timed loop issues them: one synchronisation at the end, so the
+        # kernels run at the clocks of sustained work, not of a chip that idled between launches
         reps = max(steps, 5)
-        for _ in range(reps):
-            ev[0].record()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+        for e in ev:
+            e[0].record()
             p64 = dec.decode(z, c, want=("params64",))["params64"]
-            ev[1].record()
+            e[1].record()
             grid.price(p64, out=ratio)
-            ev[2].record()
+            e[2].record()
             grid.implied_vol_checked(ratio, SPOT, "A", iv_out=iv, flags_out=flags)
-            ev[3].record()
-            torch.cuda.synchronize()
-            parts += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
-        parts /= reps
+            e[3].record()
+        torch.cuda.synchronize()
+        parts = np.mean([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in ev], axis=0)
         # the statistics block of the reference (:474-478) for every date's samples, in one call
         ok = (flags[:, 3] & 8) != 0
         afiv.ensemble_stats(iv, ok, groups=dates)
