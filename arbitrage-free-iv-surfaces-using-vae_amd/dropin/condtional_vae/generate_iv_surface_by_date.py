@@ -100,6 +100,34 @@ def ensemble_statistics(surfaces, success=None):
     return out[0], out[1], out[2], out[3]
 
 
+def generate_for_dates(model, conditioning_rows, n_samples, param_mean, param_std, spot, r, q, seeds=None,
+                       T_grid=None, logm_grid=None):
+    """The script's body for MANY dates in one pass (the notebook runs the script once per date):
+    ``conditioning_rows`` is [D, 8] (normalised), every date gets ``n_samples`` latent draws
+    (``seeds[d]`` seeds date d's draw, :439), and decode -> pricing -> implied vol -> checks ->
+    per-date statistics (:438-478) run as four launches over the D * n_samples surfaces.
+
+    Returns a dict of CUDA tensors: ``params`` [D, n, 5] float32, ``iv`` [D, n, nT, nK], ``success``
+    [D, n] bool, ``flags`` [D, n, 4] int32 and ``stats`` [D, 4, nT, nK] = mean, median, 5th and 95th
+    percentile over each date's successful surfaces (NaN where a date has none at a grid point)."""
+    T_grid = T_GRID if T_grid is None else T_grid
+    logm_grid = LOGM_GRID if logm_grid is None else logm_grid
+    rows = torch.as_tensor(np.asarray(conditioning_rows), dtype=torch.float32)
+    D = rows.shape[0]
+    if seeds is None:
+        z = torch.randn(D * n_samples, 4)
+    else:
+        z = torch.cat([torch.randn(n_samples, 4, generator=torch.Generator().manual_seed(int(sd))) for sd in seeds])
+    c = rows.repeat_interleave(n_samples, 0)
+    params32, params64 = decode_parameters(model, z.to(DEVICE), c.to(DEVICE), param_mean, param_std)
+    iv, success, flags = generate_iv_surfaces(params64, T_grid, logm_grid, spot, r, q, return_flags=True,
+                                              on_device=True)
+    stats = _afiv.ensemble_stats(iv, success, groups=D)
+    nT, nK = len(T_grid), len(logm_grid)
+    return {"params": params32.view(D, n_samples, 5), "iv": iv.view(D, n_samples, nT, nK),
+            "success": success.view(D, n_samples), "flags": flags.view(D, n_samples, 4), "stats": stats}
+
+
 def conditioning_from_csv(path, date_str):
     """Already-normalised conditioning row for ``date_str`` (nearest earlier row if absent)."""
     import csv

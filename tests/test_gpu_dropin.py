@@ -211,6 +211,37 @@ def test_statistics_on_the_device_over_the_all_dates_batch(mods, golden_dir):
         assert np.array_equal(np.nan_to_num(g, nan=-1.0), np.nan_to_num(r, nan=-1.0))
 
 
+def test_all_dates_in_one_pass_equal_the_per_date_script_body(mods, golden_dir):
+    """generate_for_dates: 500 conditioning rows x 100 seeded draws as one batch; a date's slice equals
+    what the per-date path (decode_parameters -> generate_iv_surfaces -> NumPy's statistics on the
+    successful surfaces, generate_iv_surface_by_date.py:438-478) gives for that date alone."""
+    G = mods["generate_iv_surface_by_date"]
+    model, d = _load_model(mods, golden_dir)
+    pm, ps = torch.as_tensor(d["param_mean"]).to(G.DEVICE), torch.as_tensor(d["param_std"]).to(G.DEVICE)
+    rows = d["cond_rows"]
+    out = G.generate_for_dates(model, rows, 100, pm, ps, 21000.0, 0.067, 0.0, seeds=[1000 + i for i in range(len(rows))])
+    assert out["iv"].shape == (500, 100, 8, 21) and out["stats"].shape == (500, 4, 8, 21)
+    import warnings
+    for day in (0, 137, 499):
+        z = torch.randn(100, 4, generator=torch.Generator().manual_seed(1000 + day)).to(G.DEVICE)
+        c = torch.as_tensor(rows[day:day + 1], dtype=torch.float32).repeat(100, 1).to(G.DEVICE)
+        p32, p64 = G.decode_parameters(model, z, c, pm, ps)
+        assert torch.equal(p32, out["params"][day])
+        iv, ok = G.generate_iv_surfaces(p64, G.T_GRID, G.LOGM_GRID, 21000.0, 0.067, 0.0)
+        assert np.array_equal(ok, out["success"][day].cpu().numpy())
+        assert np.array_equal(np.nan_to_num(iv, nan=-1.0), np.nan_to_num(out["iv"][day].cpu().numpy(), nan=-1.0))
+        got = out["stats"][day].cpu().numpy()
+        if ok.any():
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                valid = iv[ok]
+                ref = np.stack([np.nanmean(valid, axis=0), np.nanmedian(valid, axis=0),
+                                np.nanpercentile(valid, 5, axis=0), np.nanpercentile(valid, 95, axis=0)])
+            assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(ref, nan=-1.0))
+        else:
+            assert np.isnan(got).all()
+
+
 def test_older_twin_module_resolves_to_same_function(mods):
     """generate_surface_for_date.generate_iv_surface (reference :462-504) is the same computation
     as generate_iv_surface_by_date's (:267-322): one implementation under both names."""
