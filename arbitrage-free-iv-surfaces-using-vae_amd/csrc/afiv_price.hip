@@ -546,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         // from the constants staged in LDS at kernel start and from 32-bit index arithmetic on
         // top of one wave-uniform 64-bit base: between the two barriers around this block every
         // wave waits, so a chain of table loads from global memory here is exposed latency.
-        static_assert(ROWS * NKP * (SYM ? 2 : 1) <= THREADS, "one output item per thread");
+        static_assert(ROWS * NKP <= THREADS, "one output item per thread");
         if (have_prev) {
             const int per = nT * nK;
             const int64_t left = N - prev_chunk * SPB;
@@ -558,20 +558,19 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
             int o = tid;
             asm volatile("" : "+v"(o));
             if (SYM) {
-              if (64 * wave < SPB * MT * 2 * g.nH) {
-                // item = (row, half-strike k, direct | mirror image), numbered densely over the
-                // rows and half-strikes that exist, so that whole waves past the last item skip
-                // the block (the float quotient is exact: o + 1/2 is at least 1/(4 nH) away from a
-                // multiple of 2 nH)
-                const int twoH = 2 * g.nH;
-                const int row = (int)(((float)o + 0.5f) * (1.0f / (float)twoH));
-                const int rem = o - __mul24(row, twoH);
-                const int k = rem >> 1;
-                const bool mirror = rem & 1;
-                const int col = mirror ? nK - 1 - k : k;
+              if (64 * wave < SPB * MT * g.nH) {
+                // item = (row, half-strike k), numbered densely over the rows and half-strikes that
+                // exist, so that whole waves past the last item skip the block (the float quotient is
+                // exact: o + 1/2 is at least 1/(2 nH) away from a multiple of nH).  A thread sums the
+                // item's partial tiles once and writes both the strike and its mirror image: half the
+                // LDS reads and index arithmetic of one thread per output, and half the waves.
+                const int nH = g.nH;
+                const int row = (int)(((float)o + 0.5f) * (1.0f / (float)nH));
+                const int k = o - __mul24(row, nH);
+                const int km = nK - 1 - k;                         // the mirror image's strike index
                 const int rs = row / MT;
                 const int t = prev_tile * MT + (row - rs * MT);
-                if (row < SPB * MT && rs < nvalid && t < nT && (!mirror || col != k)) {
+                if (row < SPB * MT && rs < nvalid && t < nT) {
                     double v[4];
 #pragma unroll
                     for (int pl = 0; pl < 4; ++pl) {
@@ -581,11 +580,18 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                         v[pl] = sum;
                     }
                     // planes: 0 = C_1, 1 = C_2, 2 = S_1, 3 = S_2
-                    const double p1 = mirror ? v[0] + v[2] : v[0] - v[2];
-                    const double p2 = mirror ? v[1] + v[3] : v[1] - v[3];
-                    const double Dq = ecst[1][t], Dr = ecst[2][t], K = ecst[0][col], inv = ecst[3][t];
-                    const double call = (0.5 * Dq - 0.5 * (K * Dr)) + (p1 - K * p2);
-                    out[__mul24(rs, per) + __mul24(t, nK) + col] = inv != 0.0 ? call * inv : 0.0;
+                    const double Dq = ecst[1][t], Dr = ecst[2][t], inv = ecst[3][t];
+                    double *__restrict__ dst = out + (__mul24(rs, per) + __mul24(t, nK));
+                    {
+                        const double K = ecst[0][k];
+                        const double call = (0.5 * Dq - 0.5 * (K * Dr)) + ((v[0] - v[2]) - K * (v[1] - v[3]));
+                        dst[k] = inv != 0.0 ? call * inv : 0.0;
+                    }
+                    if (km != k) {
+                        const double K = ecst[0][km];
+                        const double call = (0.5 * Dq - 0.5 * (K * Dr)) + ((v[0] + v[2]) - K * (v[1] + v[3]));
+                        dst[km] = inv != 0.0 ? call * inv : 0.0;
+                    }
                 }
               }
             } else {
