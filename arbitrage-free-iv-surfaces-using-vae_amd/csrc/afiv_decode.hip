@@ -12,13 +12,12 @@
 
 namespace {
 
-constexpr int TS = 16;            // samples per tile
 constexpr int W1 = 12 * 32, W2 = 32 * 64, W3 = 64 * 128, W4 = 128 * 5;
 constexpr int WTOTAL = W1 + 3 * 32 + W2 + 3 * 64 + W3 + 3 * 128 + W4 + 5;
 
 // out[s][o] = act(b[o] + sum_i in[s][i] * w[i*OUT + o]) for the tile; thread = (o, sample group)
 // packed layout per hidden layer: w[IN*OUT], b[OUT], scale[OUT], shift[OUT]
-template <int IN, int OUT, int SPT, bool HIDDEN, int THREADS>
+template <int IN, int OUT, int SPT, bool HIDDEN, int THREADS, int TS>
 __device__ __forceinline__ void layer(const float *__restrict__ w,
                                       const float *__restrict__ in /*[TS][IN]*/, float *__restrict__ out /*[TS][OUT]*/,
                                       int tid)
@@ -46,12 +45,14 @@ __device__ __forceinline__ void layer(const float *__restrict__ w,
     }
 }
 
-// THREADS = 128 with 4 / 8 / 16 samples per thread in the three hidden layers: every weight read
-// feeds up to sixteen multiply-adds, the shape for batches that fill the chip.  THREADS = 512 with
+// THREADS = 256 on tiles of 32 samples with 4 / 8 / 16 samples per thread in the three hidden layers:
+// every weight read feeds up to sixteen multiply-adds, and two workgroups (79 KB of LDS each) give a
+// CU eight waves -- the shape for batches that fill the chip (128 threads on 16 samples left one
+// wave per SIMD).  THREADS = 512 on 16 samples with
 // 1 / 2 / 4 samples per thread: four times the lanes on the same tile, for batches of fewer tiles
 // than CUs, where a call's time is one tile's latency (a 100-sample decode -> surface call: 42 -> 35 us).  Same arithmetic
 // per output either way (one accumulation chain per (sample, neuron), inputs in order).
-template <int THREADS, int S1, int S2, int S3>
+template <int THREADS, int TS, int S1, int S2, int S3>
 __global__ __launch_bounds__(THREADS) void decode_kernel(DecoderView d, const float *__restrict__ z,
                                                          const float *__restrict__ c, int64_t N, int64_t c_rows,
                                                          float *__restrict__ norm_out, float *__restrict__ p32,
@@ -79,14 +80,15 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecoderView d, const fl
             bufA[s * 12 + f] = v;
         }
         __syncthreads();
-        layer<12, 32, S1, true, THREADS>(l1, bufA, bufB, tid);
+        layer<12, 32, S1, true, THREADS, TS>(l1, bufA, bufB, tid);
         __syncthreads();
-        layer<32, 64, S2, true, THREADS>(l2, bufB, bufA, tid);
+        layer<32, 64, S2, true, THREADS, TS>(l2, bufB, bufA, tid);
         __syncthreads();
-        layer<64, 128, S3, true, THREADS>(l3, bufA, bufB, tid);
+        layer<64, 128, S3, true, THREADS, TS>(l3, bufA, bufB, tid);
         __syncthreads();
-        layer<128, 5, 1, false, THREADS>(l4, bufB, bufA, tid);
+        layer<128, 5, 1, false, THREADS, TS>(l4, bufB, bufA, tid);
         __syncthreads();
+        static_assert(TS * 5 <= THREADS, "one output value per thread");
         if (tid < TS * 5) {
             const int s = tid / 5, f = tid - s * 5;
             const int64_t row = base + s;
@@ -109,13 +111,17 @@ int afiv_launch_decode(const DecoderView &d, const float *z, const float *c, int
                        float *normalized_out, float *p32, double *p64, hipStream_t s)
 {
     if (N <= 0) return 0;
-    int64_t tiles = (N + TS - 1) / TS;
-    int64_t blocks = tiles < 256 * 2 ? tiles : 256 * 2;
-    if (tiles < 256)
-        hipLaunchKernelGGL((decode_kernel<512, 1, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, s, d, z, c, N, c_rows,
+    // fewer 16-sample tiles than CUs: four times the lanes per tile; else tiles of 32 samples on 256
+    // threads, two workgroups (eight waves) per CU
+    if ((N + 15) / 16 < 256) {
+        const int64_t tiles = (N + 15) / 16;
+        hipLaunchKernelGGL((decode_kernel<512, 16, 1, 2, 4>), dim3((unsigned)tiles), dim3(512), 0, s, d, z, c, N, c_rows,
                            normalized_out, p32, p64);
-    else
-        hipLaunchKernelGGL((decode_kernel<128, 4, 8, 16>), dim3((unsigned)blocks), dim3(128), 0, s, d, z, c, N, c_rows,
+    } else {
+        const int64_t tiles = (N + 31) / 32;
+        const int64_t blocks = tiles < 256 * 2 ? tiles : 256 * 2;
+        hipLaunchKernelGGL((decode_kernel<256, 32, 4, 8, 16>), dim3((unsigned)blocks), dim3(256), 0, s, d, z, c, N, c_rows,
                            normalized_out, p32, p64);
+    }
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
 }
