@@ -13,7 +13,7 @@
 #include "laguerre144.inc"
 
 // Price ratios of afiv_surface_static pass through this array instead of caller or grid memory.
-// Every GPU the library runs on holds its own copy (32 MiB) at its own address until the process
+// Every GPU the library runs on holds its own copy (128 MiB) at its own address until the process
 // ends.  In host code the name is only a handle for hipGetSymbolAddress: kernels are given the
 // address that call returns for the current device, never the name itself.
 static __device__ __align__(256) double scratch[AFIV_STATIC_SCRATCH_DOUBLES];

@@ -61,7 +61,7 @@ enum {
 #define AFIV_MAX_MATURITIES 64   /* maturities per grid */
 #define AFIV_ENSEMBLE_ONE_SWEEP 16384  /* afiv_ensemble_stats: up to this many surfaces a column is sorted in LDS
                                         * after one sweep; larger ensembles take three or four sweeps */
-#define AFIV_STATIC_SCRATCH_DOUBLES (4 * 1024 * 1024)   /* afiv_surface_static: the array the ratios pass through (32 MiB) */
+#define AFIV_STATIC_SCRATCH_DOUBLES (16 * 1024 * 1024)   /* afiv_surface_static: the array the ratios pass through (128 MiB) */
 #define AFIV_STATIC_MAX_PIECES 1024                     /* ... and how many array-fulls one call may enqueue */
 
 typedef struct afiv_grid afiv_grid;
@@ -154,18 +154,18 @@ int afiv_surface(const afiv_grid *g, const double *params, int64_t N, double spo
                  double *ratio_out, double *iv_out, int32_t *flags_out, void *stream);
 
 /* ---- whole surface, for callers that cannot allocate: afiv_surface with ratio_out == NULL, but
- * the price ratios pass through a fixed 32 MiB array inside the library instead of a workspace the
+ * the price ratios pass through a fixed 128 MiB array inside the library instead of a workspace the
  * grid would have had to allocate, so neither the grid nor the caller provides memory for them and
  * the call itself calls no hipMalloc / hipFree or allocating routine.  No counterpart in the
  * reference: it exists for code under HIP graph capture, tight serving loops and harnesses that
  * forbid allocation.  Same results as afiv_surface, bit for bit.
- * A batch whose ratios fit the array (N * nT * nK <= AFIV_STATIC_SCRATCH_DOUBLES: 4194 surfaces of
- * 20 x 50, 24966 of 8 x 21) is one pair of launches; a larger one passes through the array in
+ * A batch whose ratios fit the array (N * nT * nK <= AFIV_STATIC_SCRATCH_DOUBLES: 16777 surfaces of
+ * 20 x 50, 99864 of 8 x 21) is one pair of launches; a larger one passes through the array in
  * pieces -- a pair of launches each, in stream order, so a million surfaces of 20 x 50 need 8.4 GB
  * for their vols and nothing for their ratios -- up to AFIV_STATIC_MAX_PIECES pieces per call,
- * beyond which the call enqueues nothing and returns AFIV_E_SCRATCH.  Small pieces cost about a
- * tenth of the big-batch rate (each ends with a pipeline drain and a launch gap); callers that can
- * allocate get that back with afiv_surface and a workspace of 100 000 surfaces or more.  Every call on a GPU
+ * beyond which the call enqueues nothing and returns AFIV_E_SCRATCH.  Pieces cost about 3 %
+ * of the one-launch rate at 20 x 50 (each ends with a pipeline drain and a launch gap; a 32 MiB array
+ * cost 12 %), which is what afiv_surface with a workspace of 131 072 surfaces costs as well.  Every call on a GPU
  * shares that GPU's array (each GPU holds its own copy until the process ends): calls that overlap
  * on one GPU -- different streams or threads -- race on it, so issue them in one stream's order.
  * Nothing in the array has to be cleared between calls.  The array's device address is looked up

@@ -43,10 +43,10 @@ for chunks in (1, 4, 8, 16, 32, 64, 1):
           f"over {reps} steps (first {first*1e3:.2f} ms) = {n/t/1e6:.2f} M surfaces/s", flush=True)
     del ratio
 
-# the same batch through the entry points that keep no ratios: the library's 32 MiB static array
-# (afiv_surface_static, pieces of 3584 surfaces) and a grid workspace of 131 072 surfaces
+# the same batch through the entry points that keep no ratios: the library's 128 MiB static array
+# (afiv_surface_static, pieces of 16128 surfaces) and a grid workspace of 131 072 surfaces
 gw = afiv.Grid(logm, tau, bench.R, bench.Q, device=dev, workspace_surfaces=131072)
-for name, fn in (("afiv_surface_static (32 MiB array)", lambda: grid.surface_static(p, bench.SPOT, "A", iv_out=iv, flags_out=fl)),
+for name, fn in (("afiv_surface_static (128 MiB array)", lambda: grid.surface_static(p, bench.SPOT, "A", iv_out=iv, flags_out=fl)),
                  ("afiv_surface, workspace of 131072 surfaces", lambda: gw.surface(p, bench.SPOT, "A", keep_ratio=False, iv_out=iv, flags_out=fl))):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); reps = 0
