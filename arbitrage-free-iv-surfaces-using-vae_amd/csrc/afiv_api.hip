@@ -42,6 +42,25 @@ int scratch_for_current_device(double **out)
     return AFIV_OK;
 }
 
+// Owns a grid under construction: whatever it holds is freed on every way out of afiv_grid_create
+// (error returns, a failed host allocation) except the successful one, which releases it.
+struct GridHold {
+    afiv_grid *g = nullptr;
+    ~GridHold()
+    {
+        if (!g) return;
+        if (g->workspace) (void)hipFree(g->workspace);
+        if (g->block) (void)hipFree(g->block);
+        delete g;
+    }
+    afiv_grid *release()
+    {
+        afiv_grid *r = g;
+        g = nullptr;
+        return r;
+    }
+};
+
 int check_grid(const afiv_grid *g)
 {
     if (!g) return AFIV_E_NULL;
@@ -64,7 +83,7 @@ const char *afiv_error_string(int code)
         case AFIV_E_NULL: return "required pointer is NULL";
         case AFIV_E_SHAPE: return "size out of supported range";
         case AFIV_E_HIP: return "HIP runtime call, kernel launch or host allocation failed";
-        case AFIV_E_ARG: return "bad argument (enum value, or object used on a different device)";
+        case AFIV_E_ARG: return "bad argument (enum value, lattice value that is not finite, or object used on a different device)";
         case AFIV_E_WORKSPACE: return "grid was created without the workspace this call needs";
         case AFIV_E_SCRATCH: return "batch exceeds what afiv_surface_static passes through its static scratch "
                                     "in one call (AFIV_STATIC_MAX_PIECES pieces of AFIV_STATIC_SCRATCH_DOUBLES / "
@@ -80,6 +99,12 @@ try {
     *out = nullptr;
     if (nK < 1 || nK > AFIV_MAX_STRIKES || nT < 1 || nT > AFIV_MAX_MATURITIES) return AFIV_E_SHAPE;
     if (workspace_surfaces < 0) return AFIV_E_SHAPE;
+    // year fractions are turned into whole days below: finite, and within the range of that conversion
+    if (!std::isfinite(r) || !std::isfinite(q)) return AFIV_E_ARG;
+    for (int k = 0; k < nK; ++k)
+        if (!std::isfinite(logm[k])) return AFIV_E_ARG;
+    for (int t = 0; t < nT; ++t)
+        if (!std::isfinite(tau[t]) || std::fabs(tau[t]) > 1e6) return AFIV_E_ARG;
     const int nKpad = (nK + 15) / 16 * 16;
 
     // Host-side constants use the host libm so that discount factors, forwards and strikes are
@@ -167,28 +192,30 @@ try {
         std::memcpy(h.data() + n_const, idx.data(), per * sizeof(unsigned short));
     }
 
-    afiv_grid *g = new (std::nothrow) afiv_grid();
+    GridHold hold;
+    hold.g = new (std::nothrow) afiv_grid();
+    afiv_grid *const g = hold.g;
     if (!g) return AFIV_E_HIP;
-    if (hipGetDevice(&g->device) != hipSuccess) { delete g; return AFIV_E_HIP; }
+    g->block = nullptr;
+    g->workspace = nullptr;
+    g->workspace_surfaces = 0;
+    if (hipGetDevice(&g->device) != hipSuccess) return AFIV_E_HIP;
     {
         // Resolve this device's static scratch here, at set-up: afiv_surface_static needs a grid of
         // the current device, so its own look-up then never runs first inside a stream capture.
         double *unused = nullptr;
         const int rc = scratch_for_current_device(&unused);
-        if (rc) { delete g; return rc; }
+        if (rc) return rc;
     }
     double *dev = nullptr;
-    if (hipMalloc((void **)&dev, nd * sizeof(double)) != hipSuccess) { delete g; return AFIV_E_HIP; }
-    if (hipMemcpy(dev, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(dev); delete g; return AFIV_E_HIP;
-    }
+    if (hipMalloc((void **)&dev, nd * sizeof(double)) != hipSuccess) return AFIV_E_HIP;
     g->block = dev;
-    g->workspace = nullptr;
-    g->workspace_surfaces = 0;
+    if (hipMemcpy(dev, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return AFIV_E_HIP;
     if (workspace_surfaces > 0) {
         const size_t bytes = (size_t)workspace_surfaces * nT * nK * sizeof(double);
         if (hipMalloc((void **)&g->workspace, bytes) != hipSuccess) {
-            (void)hipFree(dev); delete g; return AFIV_E_HIP;
+            g->workspace = nullptr;
+            return AFIV_E_HIP;
         }
         g->workspace_surfaces = workspace_surfaces;
     }
@@ -350,10 +377,8 @@ try {
                 // (the block is already on the device: these small pieces follow it)
                 if (hipMemcpy(dev + n_const + n_order, prog, sizeof(prog), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(dev + n_const + n_order + AFIV_MAX_MATURITIES / 8, need, sizeof(need),
-                              hipMemcpyHostToDevice) != hipSuccess) {
-                    if (g->workspace) (void)hipFree(g->workspace);
-                    (void)hipFree(dev); delete g; return AFIV_E_HIP;
-                }
+                              hipMemcpyHostToDevice) != hipSuccess)
+                    return AFIV_E_HIP;
                 v.step_count = 3;
             }
         }
@@ -369,10 +394,10 @@ try {
             v.step_dt[0] = step;
         }
     }
-    *out = g;
+    *out = hold.release();
     return AFIV_OK;
 } catch (...) {
-    return AFIV_E_HIP;   // host allocation of the staging tables failed; no device memory is held yet
+    return AFIV_E_HIP;   // a host allocation failed; what the grid held by then went with its holder
 }
 
 int afiv_grid_destroy(afiv_grid *g)

@@ -37,7 +37,7 @@ enum {
     AFIV_E_NULL = -1,        /* required pointer is NULL */
     AFIV_E_SHAPE = -2,       /* a size is out of the supported range */
     AFIV_E_HIP = -3,         /* a HIP runtime call, kernel launch or host allocation failed */
-    AFIV_E_ARG = -4,         /* bad enum / flag value */
+    AFIV_E_ARG = -4,         /* bad enum / flag value, lattice value that is not finite, object of another device */
     AFIV_E_WORKSPACE = -5,   /* the call needs a workspace the grid was created without */
     AFIV_E_SCRATCH = -6      /* the batch exceeds what one afiv_surface_static call passes through its scratch */
 };

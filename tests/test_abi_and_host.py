@@ -50,6 +50,15 @@ def test_error_strings_and_null_checks_without_gpu(afiv):
     assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 0, x.ctypes.data_as(dp), 4, 0.0, 0.0, 1, 0) == -2
     assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 65, x.ctypes.data_as(dp), 4, 0.0, 0.0, 1, 0) == -2
     assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 4, x.ctypes.data_as(dp), 65, 0.0, 0.0, 1, 0) == -2
+    # lattice values that are not finite (or a year fraction beyond any calendar) are rejected too,
+    # before any device call
+    for bad in (np.nan, np.inf, 1e7):
+        y = np.array([0.1, 0.2, bad, 0.4])
+        assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 4, y.ctypes.data_as(dp), 4, 0.0, 0.0, 1, 0) == -4
+    y = np.array([0.0, np.nan, 0.1, 0.2])
+    assert lib.afiv_grid_create(ctypes.byref(h), y.ctypes.data_as(dp), 4, x.ctypes.data_as(dp), 4, 0.0, 0.0, 1, 0) == -4
+    assert lib.afiv_grid_create(ctypes.byref(h), x.ctypes.data_as(dp), 4, x.ctypes.data_as(dp), 4, np.nan, 0.0, 1, 0) == -4
+    assert h.value in (None, 0)
     assert lib.afiv_price(None, None, 1, None, None) == -1
     assert lib.afiv_surface_static(None, None, 1, 1.0, 0, None, None, None) == -1
     assert b"scratch" in lib.afiv_error_string(-6)
