@@ -119,6 +119,102 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_kernel(const double *__
     }
 }
 
+// ---- groups of at most 128 surfaces (the reference's 100 samples per date) -------------------------
+// One WAVE per (group, grid point): a workgroup of 256 threads spends most of such an item in
+// barriers -- a compaction pass, the one-thread sum and 28 sorting stages of 64 exchanges each.
+// A wave holds the column in two registers per lane, compacts it into its own 1 KB of LDS in sample
+// order (ballot / prefix count), adds it up in that order on one lane, sorts the 128 padded slots with
+// the same bitonic network -- one exchange per lane and stage, wave-level ordering instead of
+// barriers -- and interpolates as above.  Same arithmetic, same results as ensemble_kernel bit for bit.
+constexpr int SMALL_N = 128;
+constexpr int SMALL_WAVES = STAT_THREADS / 64;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave are executed in order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(STAT_THREADS) void ensemble_small_kernel(const double *__restrict__ iv_all,
+                                                                      const uint8_t *__restrict__ select_all, int N,
+                                                                      int per, int64_t segments,
+                                                                      double *__restrict__ out_all)
+{
+    __shared__ double cols[SMALL_WAVES][SMALL_N];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *vals = cols[wave];
+    const double inf = __builtin_inf();
+    const int64_t items = segments * per;
+    for (int64_t item = (int64_t)blockIdx.x * SMALL_WAVES + wave; item < items; item += (int64_t)gridDim.x * SMALL_WAVES) {
+        const int64_t seg = item / per;
+        const int p = (int)(item - seg * per);
+        const double *__restrict__ iv = iv_all + seg * N * per;
+        const uint8_t *__restrict__ select = select_all ? select_all + seg * N : nullptr;
+        double *__restrict__ out = out_all + seg * 4 * per;
+        // rows lane and lane + 64
+        const int i0 = lane, i1 = lane + 64;
+        double x0 = 0.0, x1 = 0.0;
+        bool k0 = false, k1 = false;
+        if (i0 < N && (!select || select[i0])) {
+            x0 = iv[(int64_t)i0 * per + p];
+            k0 = x0 == x0;
+        }
+        if (i1 < N && (!select || select[i1])) {
+            x1 = iv[(int64_t)i1 * per + p];
+            k1 = x1 == x1;
+        }
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const int n0 = __popcll(m0), m = n0 + __popcll(m1);
+        const int o0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+        const int o1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+        wave_lds_sync();                       // the previous item's readers are done with the column
+        if (k0) vals[o0] = x0;
+        if (k1) vals[o1] = x1;
+        if (lane >= m) vals[lane] = inf;       // padding of the sort: slots m .. 127
+        if (lane + 64 >= m) vals[lane + 64] = inf;
+        wave_lds_sync();
+        // the sum in sample order (one chain, its operands read eight ahead; the padding is +inf and
+        // stays out through the count)
+        double sum = 0.0;
+        for (int r0 = 0; r0 < m; r0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = vals[(r0 + r) & (SMALL_N - 1)];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum = r0 + r < m ? sum + x[r] : sum;
+        }
+        // bitonic network over 128 slots: exchange (i, i ^ j) with i the lower index, one per lane
+        for (int k = 2; k <= SMALL_N; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int i = ((lane & ~(j - 1)) << 1) | (lane & (j - 1));      // lane-th index with bit j clear
+                const int l = i | j;
+                const double a = vals[i], b = vals[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { vals[i] = b; vals[l] = a; }      // (the stage's pairs are disjoint)
+                wave_lds_sync();
+            }
+        }
+        if (lane == 0) {
+            double mean, med, p5, p95;
+            if (m == 0) {
+                mean = med = p5 = p95 = __builtin_nan("");
+            } else {
+                mean = sum / (double)m;
+                med = (m & 1) ? vals[m / 2] : (vals[m / 2 - 1] + vals[m / 2]) / 2.0;
+                p5 = numpy_linear_quantile(vals, m, 5.0 / 100.0);
+                p95 = numpy_linear_quantile(vals, m, 95.0 / 100.0);
+            }
+            out[0 * per + p] = mean;
+            out[1 * per + p] = med;
+            out[2 * per + p] = p5;
+            out[3 * per + p] = p95;
+        }
+    }
+}
+
 // ---- ensembles larger than one LDS-resident column ---------------------------------------------
 // The same four statistics, bit for bit, for any number of surfaces, without scratch memory.  One
 // workgroup owns TILE_P adjacent grid points (half a 64-byte line of every surface row; the workgroup
@@ -614,12 +710,18 @@ int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int
         }
         return AFIV_OK;
     }
+    const int64_t items = segments * per;
+    if (N <= SMALL_N) {
+        const int64_t blocks = (items + SMALL_WAVES - 1) / SMALL_WAVES;
+        hipLaunchKernelGGL(ensemble_small_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(STAT_THREADS), 0, s,
+                           iv, select, (int)N, per, segments, out);
+        return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
+    }
     int padded = 2;
     while (padded < N) padded <<= 1;
     const size_t lds = (size_t)padded * sizeof(double);
     static DynLdsLimit raised;
     if (const int rc = afiv_ensure_dynamic_lds(reinterpret_cast<const void *>(&ensemble_kernel), lds, raised)) return rc;
-    const int64_t items = segments * per;
     hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)(items < 65536 ? items : 65536)), dim3(STAT_THREADS), lds, s, iv, select, N,
                        per, padded, segments, out);
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;

@@ -464,7 +464,7 @@ def test_wrong_dtype_and_shape_are_rejected(afiv, grid821):
         afiv.Grid(np.zeros(65), T_GRID)
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 100, 257, 3000])
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 100, 127, 128, 129, 257, 3000])
 def test_ensemble_statistics_equal_numpy_bit_for_bit(afiv, n):
     """generate_iv_surface_by_date.py:474-478 against NumPy itself (oracle.ensemble_stats)."""
     rng = np.random.default_rng(n)
@@ -493,6 +493,19 @@ def test_ensemble_statistics_select_and_limits(afiv):
     got = afiv.ensemble_stats(dev(s), torch.as_tensor(keep).cuda()).cpu().numpy()
     ref = np.stack(oracle.ensemble_stats(s[keep]))
     assert np.array_equal(got, ref)
+    # groups of at most 128 surfaces take a kernel of their own (one wave per grid point): masks that
+    # keep nothing, one row, everything; negative values and infinities sort like any other value
+    for n in (5, 64, 100, 128):
+        t = rng.standard_normal((n, 3, 7))
+        t[rng.random(t.shape) < 0.2] = np.nan
+        t[0, 0, 0], t[n - 1, 0, 1] = np.inf, -np.inf
+        for keep in (np.zeros(n, bool), np.arange(n) == n // 2, np.ones(n, bool), rng.random(n) < 0.5):
+            got = afiv.ensemble_stats(dev(t), torch.as_tensor(keep).cuda()).cpu().numpy()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.stack(oracle.ensemble_stats(t[keep])) if keep.any() else np.full((4, 3, 7), np.nan)
+            assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(ref, nan=-7.0)), (n, int(keep.sum()))
     big = 0.2 + 0.01 * rng.standard_normal((afiv.ENSEMBLE_ONE_SWEEP, 2, 3))
     got = afiv.ensemble_stats(dev(big)).cpu().numpy()
     assert np.array_equal(got, np.stack(oracle.ensemble_stats(big)))

@@ -27,3 +27,18 @@ for n, shape in ((100, (8, 21)), (16384, (8, 21)), (50000, (8, 21)), (131072, (2
         print(f"{n} x {shape[0]} x {shape[1]} ({label}): {ms:.3f} ms per call, {gb / ms * 1e3:.0f} GB/s of the stack's size "
               f"({gb:.2f} GB)", flush=True)
     del s
+
+# the per-date statistics of the all-dates batch: 500 groups of 100 surfaces in one call
+s = 0.2 + 0.05 * torch.randn((50000, 8, 21), generator=g, device="cuda", dtype=torch.float64)
+s[torch.rand(s.shape, generator=g, device="cuda") < 0.1] = float("nan")
+keep = torch.rand(50000, generator=g, device="cuda") < 0.8
+for label, sel in (("all", None), ("mask", keep)):
+    afiv.ensemble_stats(s, sel, groups=500)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(10):
+        afiv.ensemble_stats(s, sel, groups=500)
+    ev[1].record()
+    torch.cuda.synchronize()
+    print(f"500 groups of 100 x 8 x 21 ({label}): {ev[0].elapsed_time(ev[1]) / 10:.3f} ms per call", flush=True)
