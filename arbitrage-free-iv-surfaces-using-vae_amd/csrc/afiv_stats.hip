@@ -233,10 +233,7 @@ __global__ __launch_bounds__(STAT_THREADS) void ensemble_small_kernel(const doub
 //             counting: value v is the k-th smallest iff #(values < v) <= k < #(values <= v).
 // Selection is exact, so the interpolated statistics equal NumPy's whatever its partition does.
 // Three sweeps for 50 000 surfaces, four for a million; each reads every value once, coalesced.
-constexpr int TILE_P = 4;
 constexpr int SEL_THREADS = 256;
-constexpr int SEL_ROWS = SEL_THREADS / TILE_P;     // rows per sweep step
-constexpr int SEL_BLOCK = 8 * SEL_ROWS;            // rows staged per block of the in-order sum: eight per thread
 constexpr int SEL_BINS = 256;
 constexpr int SEL_TARGETS = 6;
 constexpr int SEL_CAP = 256;
@@ -312,19 +309,28 @@ __device__ __forceinline__ bool in_interval(unsigned long long key, unsigned lon
     return shift >= 64 ? true : ((key - lo) >> shift) == 0 && key >= lo;
 }
 
+// TILE_P = grid points per workgroup: 4 where that still makes 128 workgroups or more, else 2 or 1
+// (the 168 points of the reference's lattice: 168 workgroups instead of 42; the eight workgroups
+// that share a 64-byte line then each fetch it, out of the last-level cache for all but the first).
+template <int TILE_P>
 __global__ __launch_bounds__(SEL_THREADS) void ensemble_select_kernel(const double *__restrict__ iv,
                                                                       const uint8_t *__restrict__ select, int64_t N,
                                                                       int per, double *__restrict__ out)
 {
     // histograms [TILE_P][SEL_TARGETS][SEL_BINS] u32 (24 KB), later candidate lists
     // [TILE_P][SEL_TARGETS][SEL_CAP] doubles (48 KB); the in-order sum's staging block shares it
-    __shared__ __attribute__((aligned(16))) unsigned char pool[TILE_P * SEL_TARGETS * SEL_CAP * sizeof(double)];
+    // (the staging block is 8 x 256 doubles whatever TILE_P is)
+    constexpr int POOL_DOUBLES = TILE_P * SEL_TARGETS * SEL_CAP > 8 * SEL_THREADS ? TILE_P * SEL_TARGETS * SEL_CAP : 8 * SEL_THREADS;
+    __shared__ __attribute__((aligned(16))) unsigned char pool[POOL_DOUBLES * sizeof(double)];
     __shared__ SelTarget tg[TILE_P][SEL_TARGETS];
     __shared__ unsigned long long kmin[TILE_P], kmax[TILE_P];
     __shared__ long long cnt[TILE_P];
     __shared__ double sum[TILE_P];
     __shared__ int list_n[TILE_P][SEL_TARGETS];
     __shared__ int again;
+    constexpr int SEL_ROWS = SEL_THREADS / TILE_P;     // rows per sweep step
+    constexpr int SEL_BLOCK = 8 * SEL_ROWS;            // rows staged per block of the in-order sum: eight per thread
+    static_assert(SEL_BLOCK * TILE_P * sizeof(double) <= sizeof(pool), "the staging block fits the pool");
     unsigned *hist = reinterpret_cast<unsigned *>(pool);
     double *cand = reinterpret_cast<double *>(pool);
     double *stage = reinterpret_cast<double *>(pool);          // [SEL_BLOCK][TILE_P], NaN = skip
@@ -702,10 +708,19 @@ int afiv_launch_ensemble(const double *iv, const uint8_t *select, int64_t N, int
                          hipStream_t s)
 {
     if (N > AFIV_ENSEMBLE_ONE_SWEEP) {
-        const int tiles = (per + TILE_P - 1) / TILE_P;
+        // (1000 points: 250 workgroups of 4 points take 41 ms for a million surfaces, 500 of 2 points
+        // 63 ms -- narrower tiles re-fetch more lines than their parallelism buys back; 168 points:
+        // 42 workgroups of 4 take 2.0 ms for 50 000 surfaces, 168 of 1 point 1.3 ms)
+        const int tp = per >= 4 * 128 ? 4 : per >= 2 * 128 ? 2 : 1;
+        const int tiles = (per + tp - 1) / tp;
+        const dim3 blocks((unsigned)(tiles < 65536 ? tiles : 65536));
         for (int64_t g = 0; g < segments; ++g) {
-            hipLaunchKernelGGL(ensemble_select_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(SEL_THREADS), 0,
-                               s, iv + g * N * per, select ? select + g * N : nullptr, N, per, out + g * 4 * per);
+            const double *iv_g = iv + g * N * per;
+            const uint8_t *sel_g = select ? select + g * N : nullptr;
+            double *out_g = out + g * 4 * per;
+            if (tp == 4) hipLaunchKernelGGL(ensemble_select_kernel<4>, blocks, dim3(SEL_THREADS), 0, s, iv_g, sel_g, N, per, out_g);
+            else if (tp == 2) hipLaunchKernelGGL(ensemble_select_kernel<2>, blocks, dim3(SEL_THREADS), 0, s, iv_g, sel_g, N, per, out_g);
+            else hipLaunchKernelGGL(ensemble_select_kernel<1>, blocks, dim3(SEL_THREADS), 0, s, iv_g, sel_g, N, per, out_g);
             if (hipGetLastError() != hipSuccess) return AFIV_E_HIP;
         }
         return AFIV_OK;
