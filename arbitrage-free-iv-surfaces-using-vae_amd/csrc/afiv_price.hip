@@ -350,9 +350,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     const int tiles_per_split = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int tile_lo = min((int)blockIdx.y * tiles_per_split, ntiles_all);
     const int tile_hi = min(tile_lo + tiles_per_split, ntiles_all);
-    const int64_t nchunks = (N + SPB - 1) / SPB;
-    const int64_t my_chunks = blockIdx.x < nchunks ? (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int64_t total = my_chunks * (tile_hi - tile_lo);
+    // (chunk numbers and step counts fit 32 bits: the launcher checks; scalar registers are scarce here)
+    const int nchunks = (int)((N + SPB - 1) / SPB);
+    const int my_chunks = (int)blockIdx.x < nchunks ? (nchunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int total = my_chunks * (tile_hi - tile_lo);
 
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
@@ -370,16 +371,16 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     Model m = {};
     JState st0 = {}, st1 = {};
     Cx ex0 = {}, ex1 = {}, fa0 = {}, fa1 = {}, fb0 = {}, fb1 = {};   // NFAC > 0: running 1 - exp(-d T), and 1 - exp(-d step) of the steps
-    int64_t prev_chunk = 0, chunk = blockIdx.x;      // advanced with the tile counter: no division per step
+    int prev_chunk = 0, chunk = (int)blockIdx.x;     // advanced with the tile counter: no division per step
     int prev_tile = tile_lo, tile = tile_lo;
 
-    for (int64_t G = 0; G <= total; ++G) {
+    for (int G = 0; G <= total; ++G) {
         const bool have_cur = G < total, have_prev = G > 0;
         double *xw = lds + (G & 1) * XBUF;                  // written by this step's phase 1
         double *xr = lds + ((G + 1) & 1) * XBUF;            // operand block of the previous step
 
         if (have_cur && tile == tile_lo) {
-            int64_t s = chunk * SPB + sl;
+            int64_t s = (int64_t)chunk * SPB + sl;
             if (s >= N) s = N - 1;                           // spare lanes / ragged tail: never stored
             const double kappa = params[5 * s + 0], theta = params[5 * s + 1], sigma = params[5 * s + 2],
                          rho = params[5 * s + 3], v0 = params[5 * s + 4];
@@ -549,9 +550,9 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         static_assert(ROWS * NKP <= THREADS, "one output item per thread");
         if (have_prev) {
             const int per = nT * nK;
-            const int64_t left = N - prev_chunk * SPB;
+            const int64_t left = N - (int64_t)prev_chunk * SPB;
             const int nvalid = left < SPB ? (int)left : SPB;              // surfaces of the previous chunk
-            double *__restrict__ out = ratio_out + prev_chunk * (int64_t)(SPB * per);
+            double *__restrict__ out = ratio_out + (int64_t)prev_chunk * (int64_t)(SPB * per);
             // The item's indices are re-derived from the thread index at every step: hoisted out
             // of the loop they would be spilled and come back through scratch loads, here, where
             // nothing covers their latency.
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         prev_tile = tile;
         if (++tile == tile_hi) {
             tile = tile_lo;
-            chunk += gridDim.x;
+            chunk += (int)gridDim.x;
         }
     }
 }
@@ -664,6 +665,17 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     if (N <= 0) return 0;
     const int nct = g.nKpad / 16;
     if (nct < 1 || nct > 4) return AFIV_E_SHAPE;
+    // The kernel counts chunks of seven surfaces and its own steps in 32 bits: batches beyond 2^24
+    // chunks (117 million surfaces) go as several launches.
+    constexpr int64_t MAX_LAUNCH = (int64_t)SPB << 24;
+    if (N > MAX_LAUNCH) {
+        const int64_t per = (int64_t)g.nT * g.nK;
+        for (int64_t off = 0; off < N; off += MAX_LAUNCH) {
+            const int64_t n = N - off < MAX_LAUNCH ? N - off : MAX_LAUNCH;
+            if (const int rc = afiv_launch_price(g, params + 5 * off, n, ratio_out + off * per, s)) return rc;
+        }
+        return AFIV_OK;
+    }
     const int64_t chunks = (N + SPB - 1) / SPB;
     // One workgroup per CU is resident (LDS).  A workgroup's walk ends with one step that only
     // drains the pipeline (the last tile's contraction and epilogue), and a batch ends when the

@@ -204,6 +204,25 @@ def test_price_single_strike_single_maturity(afiv):
     assert np.all(np.abs(got - ref) <= price_tol(ref))
 
 
+def test_price_batch_beyond_one_launch(afiv):
+    """The pricing kernel counts chunks of seven surfaces in 32 bits; a batch beyond 2^24 chunks goes
+    as several launches.  One option per surface keeps 117 million of them at 5.6 GB: every surface
+    must come out as the same parameters do in a small batch."""
+    grid = afiv.Grid([0.03], [0.4], R, Q)
+    table = dev(sample_params(4099, 77))                      # 4099 is prime: rows shift against the chunks
+    n = 7 * (1 << 24) + 4099 * 3 + 5
+    reps = (n + 4098) // 4099
+    p = table.repeat(reps, 1)[:n].contiguous()
+    got = grid.price(p).reshape(-1)
+    small = grid.price(table).reshape(-1)
+    assert got.shape[0] == n
+    assert torch.equal(torch.nan_to_num(got[:4099 * (n // 4099)].reshape(-1, 4099), nan=-1.0),
+                       torch.nan_to_num(small, nan=-1.0).expand(n // 4099, 4099))
+    assert torch.equal(torch.nan_to_num(got[4099 * (n // 4099):], nan=-1.0),
+                       torch.nan_to_num(small[:n - 4099 * (n // 4099)], nan=-1.0))
+    del p, got
+
+
 def test_price_empty_batch(afiv, grid821):
     out = grid821.price(torch.empty((0, 5), dtype=torch.float64, device="cuda"))
     assert out.shape == (0, 8, 21)
