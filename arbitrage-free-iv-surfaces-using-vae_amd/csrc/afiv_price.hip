@@ -343,17 +343,36 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     static_assert(NEVAL >= 2, "two MFMA slots");
     const int nT = g.nT, nK = g.nK, nKpad = SYM ? g.nHpad : g.nKpad;   // nKpad: table row length
     const bool ct_live = 16 * ct < nKpad;
-    // Small batches split a chunk's maturity tiles over gridDim.y workgroups (NFAC == 0, where every
-    // maturity is evaluated on its own, and NFAC == 3, which replays the steps it skipped: the split
-    // changes no bit of the result).
-    const int ntiles_all = (nT + MT - 1) / MT;
-    const int tiles_per_split = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int tile_lo = min((int)blockIdx.y * tiles_per_split, ntiles_all);
-    const int tile_hi = min(tile_lo + tiles_per_split, ntiles_all);
+    // Workgroup b takes the chunks b, b + gridDim.x, ... and walks each through its maturity tiles --
+    // except in batches of fewer than eight chunks per workgroup whose maturities are evaluated
+    // independently (NFAC == 0) or can be re-derived (NFAC == 3 replays the steps of the program it
+    // skipped).  There the batch's steps, numbered chunk by chunk and tile by tile, are dealt out as
+    // contiguous ranges that differ by one step at most (the longer ones to the workgroups that start
+    // first) and may begin and end inside a chunk: that evens out batches of a few chunks per CU (4096
+    // surfaces of 8 x 21, two or three chunks each: -9 %) and spreads the smallest ones over more
+    // workgroups than they have chunks.  With many chunks per workgroup the extra set-up at the two
+    // ragged ends costs more than the partial chunk it evens out.  No bit of the result depends on
+    // how the steps are dealt out.
     // (chunk numbers and step counts fit 32 bits: the launcher checks; scalar registers are scarce here)
+    const int ntiles_all = (nT + MT - 1) / MT;
     const int nchunks = (int)((N + SPB - 1) / SPB);
-    const int my_chunks = (int)blockIdx.x < nchunks ? (nchunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int total = my_chunks * (tile_hi - tile_lo);
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const bool by_step = (NFAC == 0 || NFAC == 3) && (unsigned)nchunks < 8u * nb;
+    int chunk0, tile0, total, chunk_stride;
+    if (by_step) {
+        const unsigned units = (unsigned)nchunks * (unsigned)ntiles_all;
+        const unsigned share = units / nb, extra = units - share * nb;    // the first `extra` ranges are one longer
+        const unsigned u0 = b * share + (b < extra ? b : extra);
+        chunk0 = (int)(u0 / (unsigned)ntiles_all);
+        tile0 = (int)u0 - chunk0 * ntiles_all;
+        total = (int)(share + (b < extra ? 1u : 0u));
+        chunk_stride = 1;
+    } else {
+        chunk0 = (int)b;
+        tile0 = 0;
+        total = b < (unsigned)nchunks ? (int)(((unsigned)nchunks - b + nb - 1) / nb) * ntiles_all : 0;
+        chunk_stride = (int)nb;
+    }
 
     afivm::load_sincos_table(sct);
     afivm::load_log_table(sct + afivm::SINCOS_TAB_DOUBLES);
@@ -371,15 +390,16 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
     Model m = {};
     JState st0 = {}, st1 = {};
     Cx ex0 = {}, ex1 = {}, fa0 = {}, fa1 = {}, fb0 = {}, fb1 = {};   // NFAC > 0: running 1 - exp(-d T), and 1 - exp(-d step) of the steps
-    int prev_chunk = 0, chunk = (int)blockIdx.x;     // advanced with the tile counter: no division per step
-    int prev_tile = tile_lo, tile = tile_lo;
+    int prev_chunk = 0, chunk = chunk0;              // advanced with the tile counter: no division per step
+    int prev_tile = tile0, tile = tile0;
+    int tile_first = tile0;                          // where the walk enters the current chunk: tile0, then 0
 
     for (int G = 0; G <= total; ++G) {
         const bool have_cur = G < total, have_prev = G > 0;
         double *xw = lds + (G & 1) * XBUF;                  // written by this step's phase 1
         double *xr = lds + ((G + 1) & 1) * XBUF;            // operand block of the previous step
 
-        if (have_cur && tile == tile_lo) {
+        if (have_cur && tile == tile_first) {
             int64_t s = (int64_t)chunk * SPB + sl;
             if (s >= N) s = N - 1;                           // spare lanes / ragged tail: never stored
             const double kappa = params[5 * s + 0], theta = params[5 * s + 1], sigma = params[5 * s + 2],
@@ -403,8 +423,8 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
                 const afivm::coef_ptr tm = (afivm::coef_ptr)(unsigned long long)(const void *)g.term;
                 typedef const unsigned long long __attribute__((address_space(4))) *need_ptr;
                 // only the maturities this part's values descend from
-                const unsigned long long need = ((need_ptr)(unsigned long long)(const void *)g.need)[tile_lo * MT];
-                for (int t = 0; t < tile_lo * MT; ++t) {
+                const unsigned long long need = ((need_ptr)(unsigned long long)(const void *)g.need)[tile_first * MT];
+                for (int t = 0; t < tile_first * MT; ++t) {
                     if (!((need >> t) & 1ull)) continue;
                     const unsigned op = (pw[t >> 2] >> (8 * (t & 3))) & 0xffu;
                     const double T = tm[t];
@@ -612,9 +632,10 @@ __global__ __launch_bounds__(THREADS) void price_kernel(GridView g, const double
         }
         prev_chunk = chunk;
         prev_tile = tile;
-        if (++tile == tile_hi) {
-            tile = tile_lo;
-            chunk += (int)gridDim.x;
+        if (++tile == ntiles_all) {
+            tile = 0;
+            tile_first = 0;
+            chunk += chunk_stride;
         }
     }
 }
@@ -681,15 +702,14 @@ int afiv_launch_price(const GridView &g, const double *params, int64_t N, double
     // drains the pipeline (the last tile's contraction and epilogue), and a batch ends when the
     // last workgroup does: with fewer than 64 chunks per CU both are worth more than the dynamic
     // balancing of many short workgroups, so each CU gets ONE workgroup and an equal share of the
-    // chunks (50 000 surfaces on 8 x 21: -3 %); large batches keep eight rounds of workgroups.
-    const int64_t blocks = chunks < 256 * 64 ? std::min<int64_t>(chunks, 256) : 256 * 8;
-    // Fewer workgroups than CUs: a call's time is one workgroup's walk through its surfaces'
-    // maturities, two per step.  Where maturities are evaluated independently (no stepped
-    // exponential) that walk is split over several workgroups per chunk of surfaces.
+    // steps (50 000 surfaces on 8 x 21: -3 %); large batches keep eight rounds of workgroups.
+    // The share is counted in steps (a chunk's maturity tiles) where the kernel can enter a chunk at
+    // any maturity -- no stepped exponential -- and in chunks otherwise: a batch of fewer chunks than
+    // CUs is then spread over up to one workgroup per step.
     const int ntiles = (g.nT + MT - 1) / MT;
-    int64_t split = 1;
-    if ((g.step_count == 0 || g.step_count == 3) && blocks < 128) split = std::min<int64_t>(ntiles, 256 / blocks);
-    dim3 grid((unsigned)blocks, (unsigned)split), block(THREADS);
+    const int64_t units = (g.step_count == 0 || g.step_count == 3) ? chunks * ntiles : chunks;
+    const int64_t blocks = chunks < 256 * 64 ? std::min<int64_t>(units, 256) : 256 * 8;
+    dim3 grid((unsigned)blocks), block(THREADS);
 #define AFIV_LAUNCH_PRICE(NCT, NF, SY) \
     hipLaunchKernelGGL((price_kernel<NCT, NF, SY>), grid, block, 0, s, g, params, N, ratio_out)
 #define AFIV_LAUNCH_PRICE_NF(NCT, SY)                        \

@@ -398,17 +398,18 @@ def test_flags_out_of_the_wrong_shape_is_rejected(afiv, grid821):
 
 @pytest.mark.parametrize("nT", [1, 2, 7, 8, 33])
 def test_small_batches_split_maturities_without_changing_a_bit(afiv, nT):
-    """On lattices without a stepped exponential a small batch's maturities are split over several
-    workgroups per chunk of surfaces (more workgroups than the batch alone would fill).  Every
-    maturity is evaluated on its own there, so a small call must return, bit for bit, the rows a
-    large call returns for the same parameter sets."""
+    """On lattices without a stepped exponential a batch of fewer than eight chunks of surfaces per
+    workgroup is dealt out in ranges of (chunk, maturity tile) steps that begin and end inside a
+    chunk (more workgroups than the batch has chunks, and the same number of steps for each).
+    Every maturity is evaluated on its own there, so such a call must return, bit for bit, the rows
+    a call large enough to walk whole chunks returns for the same parameter sets."""
     rng = np.random.default_rng(nT)
     tau = np.sort(rng.uniform(0.02, 2.5, nT))                    # irregular: no stepping
     grid = afiv.Grid(LOGM_GRID, tau, R, Q)
     assert grid.traits["stepped"] == 0
-    p = dev(sample_params(3000, 21))
+    p = dev(sample_params(15000, 21))                            # 2143 chunks: more than eight per workgroup
     big = grid.price(p)
-    for n in (1, 6, 7, 8, 100, 700, 896, 903):                   # around the chunk size and the split limit
+    for n in (1, 6, 7, 8, 100, 700, 896, 903, 3000, 4096):       # around the chunk size; a few chunks per workgroup
         small = grid.price(p[:n].contiguous())
         assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), n
     # the whole path on a small batch
@@ -696,10 +697,11 @@ def test_sum_of_maturities_program_agrees_with_direct_evaluation(afiv):
 
 
 def test_small_batches_replay_the_program_without_changing_a_bit(afiv):
-    """A small batch on the reference's term structure splits its maturities over several workgroups,
-    each of which replays the earlier steps of the sum-of-maturities program first: the rows equal
-    those of a large call bit for bit."""
-    p = dev(sample_params(3000, 23))
+    """A batch of fewer than eight chunks per workgroup on the reference's term structure is dealt out
+    in step ranges that begin inside a chunk; such a workgroup replays the earlier steps of the
+    sum-of-maturities program first: the rows equal those of a call large enough to walk whole chunks,
+    bit for bit."""
+    p = dev(sample_params(15000, 23))
     lattices = [T_GRID] + [(np.array(days) + 0.25) / 365.0 for days in
                            ([7, 14, 30, 60], [60, 30, 90, 120, 240], [30, 30, 60, 60, 120, 180, 240, 300, 360, 720],
                             [5, 10, 20, 40, 80, 160, 320, 640, 645, 650, 660, 1300])]
@@ -707,7 +709,7 @@ def test_small_batches_replay_the_program_without_changing_a_bit(afiv):
         grid = afiv.Grid(LOGM_GRID, tau, R, Q)
         assert grid.traits["stepped"] == 3
         big = grid.price(p)
-        for n in (1, 6, 7, 8, 100, 700, 896, 903):
+        for n in (1, 6, 7, 8, 100, 700, 896, 903, 3000, 4096):
             small = grid.price(p[:n].contiguous())
             assert torch.equal(torch.nan_to_num(small, nan=-1.0), torch.nan_to_num(big[:n], nan=-1.0)), (n, len(tau))
 
