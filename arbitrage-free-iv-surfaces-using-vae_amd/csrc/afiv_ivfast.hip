@@ -29,6 +29,7 @@
 // price) every vol of a whole interval is a root in double precision; brentq's pick depends on its
 // path, this kernel returns the one its guess lands on.  Both re-price to the target to within the
 // rounding of the objective.
+#include <algorithm>
 #include "afiv_bs.h"
 #include "bachelier_table.inc"
 
@@ -397,11 +398,16 @@ int launch_fast(const GridView &g, const double *ratio, int64_t N, double spot, 
     static DynLdsLimit raised;
     if (const int rc = afiv_ensure_dynamic_lds(reinterpret_cast<const void *>(&iv_fast_kernel<CHECKS>), lds, raised))
         return rc;
-    // long-lived workgroups (each tabulates the bracket ends of the lattice first), a wave per surface;
-    // sixteen rounds of workgroups per CU: surfaces differ in their share of NaN points, and shorter
-    // workgroups even that out (four rounds: +2 %), while the tables still cost under 1 %
+    // A wave per surface, workgroups of eight.  Each workgroup tabulates the bracket ends of the whole
+    // lattice first -- two objective evaluations per lattice point, a quarter of the work of its first
+    // eight surfaces on 8 x 21 -- so a workgroup should live for four rounds of surfaces or more; on
+    // the other hand surfaces differ in their share of NaN points and second evaluations, and many
+    // short workgroups even that out.  Up to 512 workgroups (two per CU, all resident) take everything
+    // in one go; beyond, a quarter as many workgroups as rounds, 8192 at most (sixteen rounds per
+    // workgroup at a million surfaces; 2048 there: +3.6 %, and one round each on 50 000 surfaces of
+    // 8 x 21: +13 %).
     int64_t blocks = (N + FAST_WAVES - 1) / FAST_WAVES;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks > 512) blocks = std::min<int64_t>(std::max<int64_t>(blocks / 4, 512), 256 * 32);
     hipLaunchKernelGGL((iv_fast_kernel<CHECKS>), dim3((unsigned)blocks), dim3(FAST_THREADS), lds, s, g, ratio, N, spot,
                        iv_out, flags);
     return hipGetLastError() == hipSuccess ? AFIV_OK : AFIV_E_HIP;
